@@ -1,0 +1,453 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+Python face of ``acfm_oracle.c`` plus numpy/torch-CPU restatements of the reference's
+Python-level hot-path functions.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the product package
+``acfm_video_3d_reconstruction_amd`` never does.
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+Parity status: projection / losses / laplacian / solve are pinned by golden vectors made
+from the importable reference modules (tests/golden/make_golden.py); the rasterizer,
+blending and atlas sampling restate PyTorch3D 0.3.0 (absent here) and are *parity
+unpinned* beyond analytic known-answer tests.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F32P = ctypes.POINTER(ctypes.c_float)
+I64P = ctypes.POINTER(ctypes.c_int64)
+I32P = ctypes.POINTER(ctypes.c_int32)
+
+EYE_Z = 2.732  # nmr.py:144  eye = (0, 0, -2.732)  ->  T = (0, 0, 2.732)
+SIL_SIGMA = 1e-4  # nmr.py:153
+SIL_K = 20  # nmr.py:158
+SIL_BLUR = float(np.log(1.0 / 1e-4 - 1.0) * 1e-4)  # nmr.py:157
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libacfm_oracle.so")
+    src = os.path.join(_HERE, "acfm_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libacfm_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+# ----------------------------------------------------------------------------- projection
+def project(verts, cams, offset_z=0.0):
+    """geom_utils.orthographic_proj_withz (multiframe/nnutils/geom_utils.py:62-79)."""
+    verts, cams = _f32(verts), _f32(cams)
+    N, V, _ = verts.shape
+    out = np.empty_like(verts)
+    lib().oracle_project(_p(verts, F32P), _p(cams, F32P), N, V, ctypes.c_float(offset_z),
+                         _p(out, F32P))
+    return out
+
+
+def project_torch(X, cam, offset_z=0.0):
+    """Differentiable torch-CPU restatement of the same function (used for gradient
+    oracles; any dtype).  geom_utils.py:62-79, 107-152."""
+    q = cam[:, None, 3:7]
+    qc = torch.cat([q[..., :1], -q[..., 1:]], -1)
+    X4 = torch.cat([X[..., :1] * 0, X], -1)
+
+    def ham(a, b):
+        a0, a1, a2, a3 = a.unbind(-1)
+        b0, b1, b2, b3 = b.unbind(-1)
+        return torch.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3,
+                            a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                            a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1,
+                            a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0], -1)
+
+    r = ham(q.expand(-1, X.shape[1], -1), ham(X4, qc.expand(-1, X.shape[1], -1)))[..., 1:]
+    proj = cam[:, None, :1] * r
+    xy = proj[..., :2] + cam[:, None, 1:3]
+    z = proj[..., 2:] + offset_z
+    return torch.cat([xy, z], -1)
+
+
+def to_ndc(proj, flip_y=True):
+    """Camera chain of NeuralRenderer.forward (nmr.py:145-149): y *= -1 (mask/texture
+    branches only), view = X.diag(-1,1,1) + (0,0,2.732); orthographic projection is the
+    identity on xy and MeshRasterizer keeps view-space z."""
+    out = np.array(proj, dtype=np.float32, copy=True)
+    out[..., 0] = -out[..., 0]
+    if flip_y:
+        out[..., 1] = -out[..., 1]
+    out[..., 2] = out[..., 2] + np.float32(EYE_Z)
+    return out
+
+
+def face_verts_of(ndc, faces):
+    """[N,V,3] x [N,F,3] -> [N*F,3,3] packed (Meshes.verts_packed()[faces_packed()])."""
+    N = ndc.shape[0]
+    faces = np.asarray(faces)
+    if faces.ndim == 2:
+        faces = np.broadcast_to(faces, (N,) + faces.shape)
+    idx = np.arange(N)[:, None, None]
+    return np.ascontiguousarray(ndc[idx, faces].reshape(-1, 3, 3).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- rasterizer
+def rasterize(face_verts, N, H, K, blur_radius, clip_bary=False):
+    """PyTorch3D rasterize_meshes naive CPU path."""
+    face_verts = _f32(face_verts)
+    F = face_verts.shape[0] // N
+    W = H
+    p2f = np.empty((N, H, W, K), np.int64)
+    zbuf = np.empty((N, H, W, K), np.float32)
+    bary = np.empty((N, H, W, K, 3), np.float32)
+    dists = np.empty((N, H, W, K), np.float32)
+    lib().oracle_rasterize(_p(face_verts, F32P), N, F, H, W, K, ctypes.c_float(blur_radius),
+                           int(bool(clip_bary)), _p(p2f, I64P), _p(zbuf, F32P), _p(bary, F32P),
+                           _p(dists, F32P))
+    return p2f, zbuf, bary, dists
+
+
+def rasterize_backward_dists(face_verts, p2f, grad_dists):
+    """RasterizeMeshesBackwardCpu, dists path only -> [N*F,3,3]."""
+    face_verts = _f32(face_verts)
+    N, H, W, K = p2f.shape
+    F = face_verts.shape[0] // N
+    p2f = np.ascontiguousarray(p2f, dtype=np.int64)
+    grad_dists = _f32(grad_dists)
+    out = np.empty_like(face_verts)
+    lib().oracle_rasterize_backward_dists(_p(face_verts, F32P), _p(p2f, I64P),
+                                          _p(grad_dists, F32P), N, F, H, W, K, _p(out, F32P))
+    return out
+
+
+def sigmoid_alpha_blend(p2f, dists, sigma=SIL_SIGMA):
+    """SoftSilhouetteShader / sigmoid_alpha_blend -> mask [N,H,W]."""
+    K = p2f.shape[-1]
+    P = p2f.size // K
+    mask = np.empty(p2f.shape[:-1], np.float32)
+    lib().oracle_sigmoid_alpha_blend(_p(np.ascontiguousarray(p2f), I64P), _p(_f32(dists), F32P),
+                                     ctypes.c_size_t(P), K, ctypes.c_float(sigma),
+                                     _p(mask, F32P))
+    return mask
+
+
+def sigmoid_alpha_blend_backward(p2f, dists, grad_mask, sigma=SIL_SIGMA):
+    K = p2f.shape[-1]
+    P = p2f.size // K
+    out = np.empty(p2f.shape, np.float32)
+    lib().oracle_sigmoid_alpha_blend_backward(_p(np.ascontiguousarray(p2f), I64P),
+                                              _p(_f32(dists), F32P), _p(_f32(grad_mask), F32P),
+                                              ctypes.c_size_t(P), K, ctypes.c_float(sigma),
+                                              _p(out, F32P))
+    return out
+
+
+# ----------------------------------------------------------------------------- renderers
+def sil_render(verts, faces, cams, img_size, offset_z=0.0, K=SIL_K, sigma=SIL_SIGMA,
+               blur=SIL_BLUR, return_aux=False):
+    """NeuralRenderer.forward, mask branch (multiframe/nnutils/nmr.py:143-172)."""
+    N = verts.shape[0]
+    ndc = to_ndc(project(verts, cams, offset_z), flip_y=True)
+    fv = face_verts_of(ndc, faces)
+    p2f, zbuf, bary, dists = rasterize(fv, N, img_size, K, blur, clip_bary=False)
+    mask = sigmoid_alpha_blend(p2f, dists, sigma)
+    if return_aux:
+        return mask, p2f, dict(ndc=ndc, face_verts=fv, zbuf=zbuf, bary=bary, dists=dists)
+    return mask, p2f
+
+
+def sil_render_backward(verts, faces, cams, img_size, grad_mask, offset_z=0.0, K=SIL_K,
+                        sigma=SIL_SIGMA, blur=SIL_BLUR):
+    """Gradient of sum(mask * grad_mask) wrt verts [N,V,3] and cams [N,7].
+
+    Raster + blend backward in C (App-A.4/A.5); the index gather and the projection chain
+    go through torch-CPU autograd in float64 (the reference relies on autograd there)."""
+    verts = _f32(verts)
+    cams = _f32(cams)
+    N, V, _ = verts.shape
+    faces_np = np.asarray(faces)
+    if faces_np.ndim == 2:
+        faces_np = np.broadcast_to(faces_np, (N,) + faces_np.shape)
+    mask, p2f, aux = sil_render(verts, faces, cams, img_size, offset_z, K, sigma, blur, True)
+    gd = sigmoid_alpha_blend_backward(p2f, aux["dists"], grad_mask, sigma)
+    gfv = rasterize_backward_dists(aux["face_verts"], p2f, gd).reshape(N, -1, 3, 3)
+    g_ndc = np.zeros((N, V, 3), np.float64)
+    for n in range(N):
+        np.add.at(g_ndc[n], faces_np[n].reshape(-1), gfv[n].reshape(-1, 3).astype(np.float64))
+    tv = torch.tensor(verts, dtype=torch.float64, requires_grad=True)
+    tc = torch.tensor(cams, dtype=torch.float64, requires_grad=True)
+    proj = project_torch(tv, tc, offset_z)
+    ndc = torch.stack([-proj[..., 0], -proj[..., 1], proj[..., 2] + EYE_Z], -1)
+    (ndc * torch.from_numpy(g_ndc)).sum().backward()
+    return tv.grad.numpy().astype(np.float32), tc.grad.numpy().astype(np.float32), mask, p2f
+
+
+def tex_render(verts, faces, cams, atlas, img_size, offset_z=0.0, sigma=1e-4, gamma=1e-4):
+    """NeuralRenderer.forward, texture branch with atlas=True (nmr.py:173-200):
+    hard raster K=1, blur 0, clip_barycentric_coords=True (nmr.py:87-89), TexturesAtlas,
+    ambient-only Phong, softmax_rgb_blend.
+    Returns imgs [N,3,H,W], sil [N,H,W], pix_to_face [N,H,W,1], texel_idx [N,H,W]."""
+    N = verts.shape[0]
+    H = img_size
+    ndc = to_ndc(project(verts, cams, offset_z), flip_y=True)
+    fv = face_verts_of(ndc, faces)
+    p2f, zbuf, bary, dists = rasterize(fv, N, H, 1, 0.0, clip_bary=True)
+    atlas = _f32(atlas)
+    R = atlas.shape[2]
+    P = N * H * H
+    rgb = np.empty((N, H, H, 3), np.float32)
+    sil = np.empty((N, H, H), np.float32)
+    tidx = np.empty((N, H, H), np.int32)
+    lib().oracle_atlas_shade(_p(np.ascontiguousarray(p2f), I64P), _p(zbuf, F32P), _p(bary, F32P),
+                             _p(dists, F32P), _p(atlas, F32P), ctypes.c_size_t(P), R,
+                             ctypes.c_float(sigma), ctypes.c_float(gamma), _p(rgb, F32P),
+                             _p(sil, F32P), _p(tidx, I32P))
+    return np.ascontiguousarray(rgb.transpose(0, 3, 1, 2)), sil, p2f, tidx
+
+
+def tex_render_backward_atlas(tidx, grad_imgs, atlas_shape):
+    """d/d atlas of sum(imgs * grad_imgs): rgb = w * texel / (w + delta) with the blend
+    weight w = prob >= 0.5 and delta = 1e-10, i.e. d rgb / d texel = 1 to fp32 precision;
+    integer texel indexing sends no gradient to geometry."""
+    g = np.zeros((int(np.prod(atlas_shape[:-1])), 3), np.float64)
+    gi = np.asarray(grad_imgs, np.float64).transpose(0, 2, 3, 1).reshape(-1, 3)
+    t = np.asarray(tidx).reshape(-1)
+    sel = t >= 0
+    np.add.at(g, t[sel], gi[sel])
+    return g.reshape(atlas_shape).astype(np.float32)
+
+
+def of_raster(proj_verts, faces, img_size):
+    """OF_NeuralRenderer.forward (nmr.py:224-238): hard raster K=1, blur 0, no y flip,
+    verts already projected by proj_fn."""
+    N = proj_verts.shape[0]
+    ndc = to_ndc(_f32(proj_verts), flip_y=False)
+    fv = face_verts_of(ndc, faces)
+    p2f, _, _, _ = rasterize(fv, N, img_size, 1, 0.0, clip_bary=False)
+    return p2f
+
+
+# ----------------------------------------------------------------------------- losses
+# torch-CPU restatements of multiframe/nnutils/loss_utils.py (tensor in, tensor out).
+def l1_loss(pred, target, reduce=True):
+    """loss_utils.l1_loss (loss_utils.py:72-77)."""
+    loss = (pred - target).abs()
+    return loss.mean() if reduce else loss.reshape(loss.shape[0], -1).mean(1)
+
+
+def iou(pred, target, eps=1e-6, reduce=True):
+    """loss_utils.iou (loss_utils.py:18-28)."""
+    p = pred.reshape(pred.shape[0], -1)
+    t = target.reshape(target.shape[0], -1)
+    inter = (p * t).sum(1)
+    union = (p + t - p * t).sum(1) + eps
+    r = inter / union
+    return r.sum() / r.numel() if reduce else r
+
+
+def iou_loss(pred, target, reduce=True):
+    """loss_utils.iou_loss (loss_utils.py:31-32)."""
+    return 1 - iou(pred, target, reduce=reduce)
+
+
+def edt_loss(mask, edt, reduce=True):
+    """loss_utils.edt_loss (loss_utils.py:245-253)."""
+    b = mask.shape[0]
+    loss = (edt * mask[:, None]).reshape(b, -1).mean(-1)
+    return loss.mean() if reduce else loss
+
+
+def visible_vertices(faces, pix_to_face0, nv):
+    """Visible-vertex mask shared by bds_loss (loss_utils.py:214-224) and
+    optical_flow_loss (:432-443): verts of every face that appears in pix_to_face[...,0]."""
+    bt = faces.shape[0]
+    vis = torch.zeros(bt * nv)
+    faces_ = (faces + torch.arange(bt)[:, None, None] * nv).reshape(-1, 3)
+    fm = pix_to_face0.reshape(-1)
+    fm = fm[fm >= 0].long()
+    vis[faces_[fm].reshape(-1).unique()] = 1
+    return vis.reshape(bt, nv)
+
+
+def bds_loss(verts, bds, faces, pix_to_face, reduce=True):
+    """loss_utils.bds_loss (loss_utils.py:204-237) with all boundary points kept
+    (bds.shape[1] <= n_samples, so the randperm at :211 is a pure permutation)."""
+    bt, nv, _ = verts.shape
+    bds_v, bds_m = bds[..., :-1], bds[..., -1]
+    vis = visible_vertices(faces, pix_to_face[..., 0], nv)
+    dist = torch.cdist(bds_v, verts) ** 2
+    dist = (1 - vis[:, None]) * 1000 + vis[:, None] * dist
+    min_d = dist.min(-1)[0]
+    loss = (min_d * bds_m).sum(-1)
+    return loss.mean() if reduce else loss
+
+
+def locally_rigid(verts, verts_t, edges):
+    """loss_utils.locally_rigid_fn (loss_utils.py:150-164) on padded verts [N,V,3] with a
+    shared edge list [E,2] (Meshes.edges_packed of N identical topologies)."""
+    N = verts.shape[0]
+    d = (verts[:, edges[:, 0]] - verts[:, edges[:, 1]]).norm(dim=-1)
+    dt = (verts_t[:, edges[:, 0]] - verts_t[:, edges[:, 1]]).norm(dim=-1)
+    return ((d - dt) ** 2).sum() / N
+
+
+def kp_l2_loss(kp_pred, kp_gt, reduction="mean"):
+    """loss_utils.kp_l2_loss (loss_utils.py:341-356)."""
+    vis = (kp_gt[:, :, 2] > 0).float()
+    loss = (kp_pred - kp_gt[:, :, :2]).abs().sum(-1) * vis
+    loss = loss.mean(-1) / (vis.mean(-1) + 1e-4)
+    return loss.mean() if reduction == "mean" else loss
+
+
+def deform_l2reg(V):
+    """loss_utils.deform_l2reg (loss_utils.py:322-327)."""
+    return V.reshape(-1, V.shape[2]).norm(p=2, dim=1).mean()
+
+
+def quat_loss_geodesic(q1, q2):
+    """loss_utils.quat_loss_geodesic (loss_utils.py:262-277)."""
+    a0, a1, a2, a3 = q1.unbind(-1)
+    b0, b1, b2, b3 = q2[:, 0], -q2[:, 1], -q2[:, 2], -q2[:, 3]
+    w = a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3
+    return (1 - w.abs())[:, None]
+
+
+def camera_loss(cam_pred, cam_gt, margin):
+    """loss_utils.camera_loss (loss_utils.py:280-289); hinge_loss (:256-259) restated
+    without the hard-coded .cuda()."""
+    rot = torch.clamp(quat_loss_geodesic(cam_pred[:, -4:], cam_gt[:, -4:]) - margin, min=0)
+    st = torch.clamp(((cam_pred[:, :3] - cam_gt[:, :3]) ** 2).reshape(-1) - margin, min=0)
+    return rot.mean() + st.mean()
+
+
+def optical_flow_loss(meshes, faces, cams, flows, pix_to_face=None, reduce=True):
+    """loss_utils.optical_flow_loss (loss_utils.py:419-474).  meshes [b,t,V,3],
+    faces [b,t,F,3], cams [b*t,7], flows [b,t,H,W,2]; pix_to_face None -> hard raster of
+    the projected verts through OF_NeuralRenderer (nmr.py:224-238)."""
+    H, W = flows.shape[2:4]
+    b, t, nv, _ = meshes.shape
+    bt = b * t
+    pts = project_torch(meshes.reshape(bt, nv, 3), cams.reshape(bt, -1))
+    with torch.no_grad():
+        f_ = faces.reshape(bt, -1, 3).long()
+        if pix_to_face is None:
+            p2f = torch.from_numpy(of_raster(pts.detach().float().numpy(), f_.numpy(), H))
+        else:
+            p2f = pix_to_face[..., :1].long()
+        vis = visible_vertices(f_, p2f[..., 0], nv).reshape(b, t, nv)
+    pxy = pts[..., :2]
+    fl = flows.reshape(bt, H, W, 2).permute(0, 3, 1, 2)
+    samp = torch.nn.functional.grid_sample(fl, pxy[:, :, None, :].to(fl.dtype),
+                                           align_corners=False, mode="nearest")
+    samp = samp[..., 0].permute(0, 2, 1).reshape(b, t, nv, 2)
+    pix = W * (pxy.reshape(b, t, nv, 2) + 1) / 2
+    of_pred = pix[:, :-1] - pix[:, 1:]
+    vis = ((samp.abs().sum(-1) != 0) & vis.bool()).float()[:, 1:].detach()
+    gt = vis[..., None] * samp[:, 1:]
+    of_pred = vis[..., None] * of_pred
+    loss = (gt[..., 0] - of_pred[..., 0]).abs().sum(-1) + (gt[..., 1] - of_pred[..., 1]).abs().sum(-1)
+    loss = loss / H / (vis.sum(-1) + 1)
+    if reduce:
+        loss = loss.sum()
+    return loss, of_pred, vis
+
+
+# ----------------------------------------------------------------------------- mesh ops
+def edges_packed(faces):
+    """Meshes.edges_packed for one mesh: unique sorted (min,max) pairs."""
+    f = np.asarray(faces)
+    e = np.concatenate([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)
+    e = np.sort(e, 1)
+    return np.unique(e, axis=0)
+
+
+def laplacian_cot(verts, faces):
+    """geom_utils.mesh_laplacian(meshes, 'cot') (geom_utils.py:158-254, 257-324) for one
+    mesh -> dense L [V,V] (torch, dtype of verts)."""
+    V = verts.shape[0]
+    fv = verts[faces]
+    v0, v1, v2 = fv[:, 0], fv[:, 1], fv[:, 2]
+    A = (v1 - v2).norm(dim=1)
+    B = (v0 - v2).norm(dim=1)
+    C = (v0 - v1).norm(dim=1)
+    s = 0.5 * (A + B + C)
+    area = (s * (s - A) * (s - B) * (s - C)).clamp(min=1e-12).sqrt()
+    A2, B2, C2 = A * A, B * B, C * C
+    cot = torch.stack([(B2 + C2 - A2) / area, (A2 + C2 - B2) / area, (A2 + B2 - C2) / area], 1) / 4.0
+    ii = faces[:, [1, 2, 0]].reshape(-1)
+    jj = faces[:, [2, 0, 1]].reshape(-1)
+    W = torch.zeros(V, V, dtype=verts.dtype)
+    W.index_put_((ii, jj), cot.reshape(-1), accumulate=True)
+    W = W + W.t()
+    return W - torch.diag(W.sum(1))
+
+
+def laplacian_smoothing_cot(verts, faces):
+    """pytorch3d.loss.mesh_laplacian_smoothing(meshes, 'cot') for padded
+    verts [N,V,3] sharing one face list [F,3]."""
+    N, V, _ = verts.shape
+    total = 0
+    for n in range(N):
+        with torch.no_grad():
+            L = laplacian_cot(verts[n].detach(), faces)
+            W = L - torch.diag(torch.diagonal(L))
+            rs = W.sum(1)
+            nw = torch.where(rs > 0, 1.0 / rs, torch.zeros_like(rs))
+        lv = (W @ verts[n]) * nw[:, None] - verts[n]
+        total = total + lv.norm(dim=1).sum() / V
+    return total / N
+
+
+def deform_solve(lbs_logits, mean_v, delta, L, dtype=torch.float64):
+    """Deformation solve exactly as written in the reference (multiframe/main.py:586-609):
+    A = softmax(lbs, 0)^T; delta_v = A v + delta; M = L^T L + A^T A;
+    b = L^T (L v) + A^T delta_v; pred_v = cholesky_solve(b, cholesky(M)).
+    Evaluated in ``dtype`` (float64 = the parity target)."""
+    lbs_logits, mean_v, delta, L = (x.to(dtype) for x in (lbs_logits, mean_v, delta, L))
+    A = torch.softmax(lbs_logits, dim=0).t()
+    dv = (A @ mean_v)[None] + delta
+    M = L.t() @ L + A.t() @ A
+    b = (L.t() @ (L @ mean_v))[None] + A.t()[None] @ dv
+    u = torch.linalg.cholesky(M)
+    return torch.cholesky_solve(b, u[None].expand(b.shape[0], -1, -1))
+
+
+def subdivide(verts, faces):
+    """pytorch3d.ops.SubdivideMeshes for one mesh."""
+    verts = np.asarray(verts)
+    faces = np.asarray(faces)
+    V = verts.shape[0]
+    edges = edges_packed(faces)
+    key = {(int(a), int(b)): i for i, (a, b) in enumerate(edges)}
+
+    def eid(a, b):
+        return key[(int(min(a, b)), int(max(a, b)))] + V
+
+    new_v = np.concatenate([verts, 0.5 * (verts[edges[:, 0]] + verts[edges[:, 1]])], 0)
+    f0, f1, f2, f3 = [], [], [], []
+    for (a, b, c) in faces:
+        e0, e1, e2 = eid(b, c), eid(a, c), eid(a, b)
+        f0.append((a, e2, e1))
+        f1.append((b, e0, e2))
+        f2.append((c, e1, e0))
+        f3.append((e0, e1, e2))
+    return new_v.astype(verts.dtype), np.array(f0 + f1 + f2 + f3, dtype=faces.dtype)
