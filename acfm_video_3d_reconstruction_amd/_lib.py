@@ -1,0 +1,86 @@
+"""ctypes binding of libacfm_hip.so (C ABI declared in include/acfm_hip.h).
+
+This is the only place the shared library is loaded.  It fails loudly: a missing library or
+a CPU tensor is an error, never a silent fallback."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libacfm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/acfm_hip.h
+SIGNATURES = {
+    "acfm_version": (_i, []),
+    "acfm_arch": (ctypes.c_char_p, []),
+    "acfm_prof_enable": (_i, [_i]),
+    "acfm_prof_collect": (_i, [_vp, _vp, _i]),
+    "acfm_prof_name": (ctypes.c_char_p, [_i]),
+    "acfm_project": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
+    "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i]),
+    "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp,
+                               _sz, _vp]),
+    "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "acfm_tex_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
+                              _vp, _sz, _vp]),
+    "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_visible_vertices": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_bds_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_bds_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+_ERR = {1: "ACFM_E_BADARG (shape/parameter outside what the kernels support)",
+        2: "ACFM_E_LAUNCH (HIP launch failed)", 3: "ACFM_E_WORKSPACE (workspace too small)"}
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile libacfm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=out)
+    return SO_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "libacfm_hip.so is missing (%s). Build it with `python -c \"import __graft_entry__ "
+                "as g; g.build()\"` or `make -C %s`. There is no CPU fallback." % (SO_PATH, CSRC))
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "error %d" % rc)))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("acfm_video_3d_reconstruction_amd ops run on the GPU only "
+                               "(got a %s tensor); there is no CPU fallback" % t.device)

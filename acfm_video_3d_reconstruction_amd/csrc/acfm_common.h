@@ -1,0 +1,134 @@
+// Shared device helpers for the gfx950 kernels of libacfm_hip.so.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): fp32, every multiply and add rounds
+// separately (-ffp-contract=off + the pragma below), IEEE division (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  That is what makes face indices bit-identical
+// to the CPU oracle and to the reference's chain of separate torch kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/acfm_hip.h"
+
+#pragma clang fp contract(off)
+
+#define ACFM_K_EPS 1e-8f   // PyTorch3D kEpsilon
+#define ACFM_EYE_Z 2.732f  // nmr.py:144: eye=(0,0,-2.732) -> T=(0,0,2.732)
+#define ACFM_WAVE 64
+
+#define ACFM_CHECK_LAUNCH()                        \
+  do {                                             \
+    if (hipGetLastError() != hipSuccess) return ACFM_E_LAUNCH; \
+  } while (0)
+
+namespace acfm {
+
+// per-kernel hipEvent bracketing (acfm_prof_* in include/acfm_hip.h); state lives in acfm_raster.hip
+void prof_begin(int id, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+  hipStream_t st;
+  ProfScope(int id, hipStream_t s) : st(s) { prof_begin(id, s); }
+  ~ProfScope() { prof_end(st); }
+};
+
+// Workspace carve-up shared by every raster entry point (acfm_raster_workspace_bytes).
+struct RasterWs {
+  float* ndc;      // [N,V,3] NDC x, NDC y, view z
+  float4* recA;    // [N,F] (x0,y0,x1,y1)
+  float4* recB;    // [N,F] (x2,y2,z0,z1)
+  float4* recC;    // [N,F] (z2, area, -, -)
+  float4* box;     // [N,F] (xmin,xmax,ymin,ymax), blur margin included; degenerate = (inf,-inf,inf,-inf)
+  int4* vidx;      // [N,F] (i0,i1,i2,-)
+  float4* mbox;    // [N]   union of the face boxes
+  float* grad_ndc; // [N,V,2]
+  size_t bytes;
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline RasterWs carve_ws(void* base, int N, int V, int F) {
+  RasterWs w;
+  char* p = (char*)base;
+  size_t o = 0;
+  w.ndc = (float*)(p + o);      o += align256(sizeof(float) * 3 * (size_t)N * V);
+  w.recA = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
+  w.recB = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
+  w.recC = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
+  w.box = (float4*)(p + o);     o += align256(sizeof(float4) * (size_t)N * F);
+  w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
+  w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N);
+  w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
+  w.bytes = o;
+  return w;
+}
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// PointLineDistanceForward: squared distance from p to segment ab.
+__device__ __forceinline__ float point_line_dist(float px, float py, float ax, float ay, float bx,
+                                                 float by) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= ACFM_K_EPS) {
+    const float dx = px - bx, dy = py - by;
+    return dx * dx + dy * dy;
+  }
+  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float qx = ax + t * bax, qy = ay + t * bay;
+  const float dx = qx - px, dy = qy - py;
+  return dx * dx + dy * dy;
+}
+
+// PixToNdc
+__device__ __forceinline__ float pix_to_ndc(int i, int S) {
+  return -1.0f + (2.0f * (float)i + 1.0f) / (float)S;
+}
+
+// geom_utils.orthographic_proj_withz (geom_utils.py:62-79) for one point; c = cams row.
+__device__ __forceinline__ void project_point(const float* __restrict__ c, float x, float y, float z,
+                                              float offset_z, float& ox, float& oy, float& oz) {
+  const float q0 = c[3], q1 = c[4], q2 = c[5], q3 = c[6];
+  const float c1 = -1.0f * q1, c2 = -1.0f * q2, c3 = -1.0f * q3;
+  const float X0 = x * 0.0f;
+  const float t0 = X0 * q0 - x * c1 - y * c2 - z * c3;
+  const float t1 = X0 * c1 + x * q0 + y * c3 - z * c2;
+  const float t2 = X0 * c2 - x * c3 + y * q0 + z * c1;
+  const float t3 = X0 * c3 + x * c2 - y * c1 + z * q0;
+  const float r1 = q0 * t1 + q1 * t0 + q2 * t3 - q3 * t2;
+  const float r2 = q0 * t2 - q1 * t3 + q2 * t0 + q3 * t1;
+  const float r3 = q0 * t3 + q1 * t2 - q2 * t1 + q3 * t0;
+  ox = c[0] * r1 + c[1];
+  oy = c[0] * r2 + c[2];
+  oz = c[0] * r3 + offset_z;
+}
+
+__device__ __forceinline__ float sigmoid_neg(float sd, float sigma) {
+  // sigmoid(-sd / sigma) = 1 / (1 + exp(sd / sigma))
+  return 1.0f / (1.0f + expf(sd / sigma));
+}
+
+// wave64 sum via DPP-free shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace acfm

@@ -1,0 +1,213 @@
+// Reprojection-loss kernels for gfx950 (HBM-bound streaming reductions):
+//   fused silhouette losses  <- loss_utils.l1_loss / iou / edt_loss   (loss_utils.py:18-32, 72-77, 245-253)
+//   visible-vertex bitmap    <- loss_utils.bds_loss :214-224 / optical_flow_loss :432-443
+//   boundary loss            <- loss_utils.bds_loss :204-237
+#include "acfm_common.h"
+
+namespace acfm {
+
+constexpr int LTPB = 256;
+constexpr int PIX_PER_BLOCK = 4096;  // 16 px per thread: 4 x float4
+
+// out[n] += (sum|m-gt|/HW, sum m*gt, sum(m+gt-m*gt), sum edt*m/HW); one pass over the mask.
+__global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ mask,
+                                                      const float* __restrict__ gt,
+                                                      const float* __restrict__ edt, int HW,
+                                                      float* __restrict__ out) {
+  __shared__ float s_red[4][4];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const size_t base = (size_t)n * HW;
+  const int start = blockIdx.x * PIX_PER_BLOCK;
+  const int end = min(start + PIX_PER_BLOCK, HW);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const bool vec = ((HW & 3) == 0);
+  if (vec) {
+    for (int i = start + tid * 4; i < end; i += LTPB * 4) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + base + i);
+      float4 g = make_float4(0, 0, 0, 0), e = make_float4(0, 0, 0, 0);
+      if (gt) g = *reinterpret_cast<const float4*>(gt + base + i);
+      if (edt) e = *reinterpret_cast<const float4*>(edt + base + i);
+      a0 += fabsf(m.x - g.x) + fabsf(m.y - g.y) + fabsf(m.z - g.z) + fabsf(m.w - g.w);
+      a1 += m.x * g.x + m.y * g.y + m.z * g.z + m.w * g.w;
+      a2 += (m.x + g.x - m.x * g.x) + (m.y + g.y - m.y * g.y) + (m.z + g.z - m.z * g.z) +
+            (m.w + g.w - m.w * g.w);
+      a3 += e.x * m.x + e.y * m.y + e.z * m.z + e.w * m.w;
+    }
+  } else {
+    for (int i = start + tid; i < end; i += LTPB) {
+      const float m = mask[base + i], g = gt ? gt[base + i] : 0.f, e = edt ? edt[base + i] : 0.f;
+      a0 += fabsf(m - g); a1 += m * g; a2 += m + g - m * g; a3 += e * m;
+    }
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) { s_red[w][0] = a0; s_red[w][1] = a1; s_red[w][2] = a2; s_red[w][3] = a3; }
+  __syncthreads();
+  if (tid < 4) {
+    float v = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (tid == 0 || tid == 3) v = v / (float)HW;
+    atomicAdd(&out[4 * (size_t)n + tid], v);
+  }
+}
+
+// grad_mask = go0*sign(m-gt)/HW + go1*gt + go2*(1-gt) + go3*edt/HW
+__global__ __launch_bounds__(LTPB) void k_mask_losses_bwd(const float* __restrict__ mask,
+                                                          const float* __restrict__ gt,
+                                                          const float* __restrict__ edt,
+                                                          const float* __restrict__ go, int HW,
+                                                          float* __restrict__ grad_mask) {
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * HW;
+  const float inv = 1.0f / (float)HW;
+  const float g0 = go[4 * n] * inv, g1 = go[4 * n + 1], g2 = go[4 * n + 2], g3 = go[4 * n + 3] * inv;
+  const int start = blockIdx.x * PIX_PER_BLOCK;
+  const int end = min(start + PIX_PER_BLOCK, HW);
+  for (int i = start + threadIdx.x; i < end; i += LTPB) {
+    const float m = mask[base + i], g = gt ? gt[base + i] : 0.f, e = edt ? edt[base + i] : 0.f;
+    const float df = m - g;
+    const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+    grad_mask[base + i] = g0 * sgn + g1 * g + g2 * (1.0f - g) + g3 * e;
+  }
+}
+
+__global__ void k_visible(const int64_t* __restrict__ p2f, const int64_t* __restrict__ faces, int V,
+                          int F, int HW, int K, uint8_t* __restrict__ vis) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int64_t fp = p2f[((size_t)n * HW + p) * K];
+  if (fp < 0) return;
+  int f = (int)(fp - (int64_t)n * F);
+  f = min(max(f, 0), F - 1);
+  const int64_t* fi = faces + ((size_t)n * F + f) * 3;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int v = min(max((int)fi[j], 0), V - 1);
+    vis[(size_t)n * V + v] = 1;
+  }
+}
+
+__global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ verts_xy,
+                                                   const float* __restrict__ bds,
+                                                   const uint8_t* __restrict__ vis, int V, int P,
+                                                   float* __restrict__ loss, int32_t* __restrict__ argmin) {
+  extern __shared__ float s_xy[];  // [V][2], x = +inf for invisible verts
+  __shared__ float s_red[4];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  for (int v = tid; v < V; v += LTPB) {
+    const bool vz = vis[(size_t)n * V + v] != 0;
+    s_xy[2 * v] = vz ? verts_xy[((size_t)n * V + v) * 2] : __builtin_inff();
+    s_xy[2 * v + 1] = vz ? verts_xy[((size_t)n * V + v) * 2 + 1] : 0.f;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * LTPB + tid;
+  float contrib = 0.f;
+  if (p < P) {
+    const float* b = bds + ((size_t)n * P + p) * 3;
+    const float bx = b[0], by = b[1], bm = b[2];
+    float best = 1000.0f;  // loss_utils.py:228: invisible vertices sit at distance 1000
+    int bi = -1;
+    for (int v = 0; v < V; ++v) {
+      const float dx = bx - s_xy[2 * v], dy = by - s_xy[2 * v + 1];
+      const float d = dx * dx + dy * dy;
+      if (d < best) { best = d; bi = v; }
+    }
+    contrib = best * bm;
+    argmin[(size_t)n * P + p] = bi;
+  }
+  contrib = wave_sum(contrib);
+  if ((tid & 63) == 0) s_red[tid >> 6] = contrib;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&loss[n], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+__global__ void k_bds_loss_bwd(const float* __restrict__ verts_xy, const float* __restrict__ bds,
+                               const int32_t* __restrict__ argmin, const float* __restrict__ gl, int V,
+                               int P, float* __restrict__ gv) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int v = argmin[(size_t)n * P + p];
+  if (v < 0) return;
+  const float* b = bds + ((size_t)n * P + p) * 3;
+  const float g = gl[n] * b[2];
+  if (g == 0.f) return;
+  const float* x = verts_xy + ((size_t)n * V + v) * 2;
+  atomicAdd(&gv[((size_t)n * V + v) * 2], 2.0f * (x[0] - b[0]) * g);
+  atomicAdd(&gv[((size_t)n * V + v) * 2 + 1], 2.0f * (x[1] - b[1]) * g);
+}
+
+}  // namespace acfm
+
+using namespace acfm;
+
+extern "C" {
+
+int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW, float* out,
+                     void* stream) {
+  if (!mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * 4 * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  const int chunks = (HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
+  ProfScope ps(ACFM_PROF_MASK_LOSS, st);
+  hipLaunchKernelGGL(k_mask_losses, dim3(chunks, N), dim3(LTPB), 0, st, mask, gt, edt, HW, out);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_mask_losses_backward(const float* mask, const float* gt, const float* edt,
+                              const float* grad_out, int N, int HW, float* grad_mask, void* stream) {
+  if (!mask || !grad_out || !grad_mask || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+  const int chunks = (HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
+  ProfScope ps(ACFM_PROF_MASK_LOSS_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_mask_losses_bwd, dim3(chunks, N), dim3(LTPB), 0, (hipStream_t)stream, mask, gt,
+                     edt, grad_out, HW, grad_mask);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_visible_vertices(const int64_t* pix_to_face, const int64_t* faces, int N, int V, int F, int HW,
+                          int K, uint8_t* vis, void* stream) {
+  if (!pix_to_face || !faces || !vis || N <= 0 || N > 65535 || V <= 0 || F <= 0 || HW <= 0 || K <= 0)
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  ProfScope ps(ACFM_PROF_VISIBLE, st);
+  hipLaunchKernelGGL(k_visible, dim3((HW + 255) / 256, N), dim3(256), 0, st, pix_to_face, faces, V, F,
+                     HW, K, vis);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, int N, int V, int P,
+                  float* loss, int32_t* argmin, void* stream) {
+  if (!verts_xy || !bds || !vis || !loss || !argmin || N <= 0 || N > 65535 || V <= 0 || P <= 0)
+    return ACFM_E_BADARG;
+  const size_t lds = sizeof(float) * 2 * (size_t)V;
+  if (lds > 150 * 1024) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  ProfScope ps(ACFM_PROF_BDS, st);
+  hipLaunchKernelGGL(k_bds_loss, dim3((P + LTPB - 1) / LTPB, N), dim3(LTPB), lds, st, verts_xy, bds, vis,
+                     V, P, loss, argmin);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_t* argmin,
+                           const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
+                           void* stream) {
+  if (!verts_xy || !bds || !argmin || !grad_loss || !grad_verts_xy || N <= 0 || N > 65535 || V <= 0 ||
+      P <= 0)
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_verts_xy, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
+    return ACFM_E_LAUNCH;
+  ProfScope ps(ACFM_PROF_BDS_BWD, st);
+  hipLaunchKernelGGL(k_bds_loss_bwd, dim3((P + 255) / 256, N), dim3(256), 0, st, verts_xy, bds, argmin,
+                     grad_loss, V, P, grad_verts_xy);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Drop-in for the reference's multiframe/nnutils/nmr.py (same classes, same forward
+signatures, same return shapes/dtypes) running on the gfx950 kernels of libacfm_hip.so.
+
+reference                                   here
+NeuralRenderer.forward (nmr.py:143-200)     ops.sil_render / ops.tex_render
+NeuralRenderer.project_points (:127-129)    ops.project
+OF_NeuralRenderer.forward (:224-238)        ops.hard_raster
+"""
+import math
+
+import torch
+
+from .. import ops
+from . import geom_utils
+
+
+class NeuralRenderer(torch.nn.Module):
+    """Soft-silhouette (K=20, blur ln(9999)*1e-4, sigma 1e-4) and atlas-texture (K=1)
+    renderer with a weak-perspective camera.  Stateless and replicable (the reference wraps
+    it in nn.DataParallel, main.py:183-193); honours the input tensors' device and the
+    current HIP stream."""
+
+    def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4):
+        super().__init__()
+        self.img_size = img_size
+        self.faces_per_pixel = faces_per_pixel          # nmr.py:158
+        self.sigma = sigma                              # nmr.py:153
+        self.gamma = gamma
+        self.blur_radius = math.log(1. / 1e-4 - 1.) * sigma  # nmr.py:157
+        self.proj_fn = geom_utils.orthographic_proj_withz    # nmr.py:117
+        self.offset_z = 0.                                   # nmr.py:119 (monocular: 5.)
+
+    def ambient_light_only(self):  # nmr.py:121 (no-op in the reference too)
+        return
+
+    def set_bgcolor(self, color):  # nmr.py:124
+        return
+
+    def project_points(self, verts, cams):  # nmr.py:127-129
+        return self.proj_fn(verts, cams)[:, :, :2]
+
+    def rasterize_of(self, verts, faces, R=None, T=None):
+        """nmr.py:131-141: hard K=1 raster of already-projected verts.  The reference passes
+        the look_at R/T of OF_NeuralRenderer; only that fixed view is supported."""
+        return ops.hard_raster(verts, faces, self.img_size)
+
+    def forward(self, vertices, faces, cams, textures=None, atlas=True):
+        if textures is None:
+            self.mask_only = True
+            masks, pix_to_face = ops.sil_render(vertices, faces, cams, self.img_size,
+                                                K=self.faces_per_pixel, blur=self.blur_radius,
+                                                sigma=self.sigma, offset_z=self.offset_z)
+            return masks, pix_to_face
+        self.mask_only = False
+        if not atlas:
+            raise NotImplementedError("per-vertex RGB textures (atlas=False, nmr.py:177-179) are a "
+                                      "visualisation-only path and are not built yet")
+        imgs, sil, pix_to_face = ops.tex_render(vertices, faces, cams, textures.to(vertices.device),
+                                                self.img_size, sigma=1e-4, gamma=1e-4,
+                                                offset_z=self.offset_z)
+        return imgs, sil, pix_to_face
+
+
+class OF_NeuralRenderer(torch.nn.Module):
+    """nmr.py:203-238: visibility rasteriser for the optical-flow loss."""
+
+    def __init__(self, img_size=256):
+        super().__init__()
+        self.img_size = img_size
+        self.proj_fn = geom_utils.orthographic_proj_withz
+        self.offset_z = 5.
+
+    def project_points(self, verts, cams):
+        return self.proj_fn(verts, cams)[:, :, :2]
+
+    def forward(self, verts, faces):
+        return ops.hard_raster(verts, faces, self.img_size)

@@ -1,0 +1,268 @@
+"""torch.autograd bindings of the C ABI (include/acfm_hip.h).
+
+torch is used here for device memory, streams and autograd bookkeeping only; every op body
+is one or more stream-ordered calls into libacfm_hip.so."""
+import math
+
+import torch
+
+from . import _lib
+
+SIL_K = 20  # nmr.py:158
+SIL_SIGMA = 1e-4  # nmr.py:153
+SIL_BLUR = math.log(1.0 / 1e-4 - 1.0) * 1e-4  # nmr.py:157
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def expand_faces(faces, N):
+    """faces [F,3] / [1,F,3] / [N,F,3] -> contiguous int64 [N,F,3] on the same device."""
+    if faces.dim() == 2:
+        faces = faces[None]
+    if faces.shape[0] != N:
+        if faces.shape[0] != 1:
+            raise ValueError("faces batch %d does not match %d meshes" % (faces.shape[0], N))
+        faces = faces.expand(N, -1, -1)
+    return faces.to(torch.int64).contiguous()
+
+
+def _workspace(N, V, F, device):
+    nbytes = _lib.lib().acfm_raster_workspace_bytes(N, V, F)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+# ------------------------------------------------------------------------------ projection
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, cams, offset_z):
+        _lib.require_gpu(verts, cams)
+        v, c = _f32c(verts), _f32c(cams)
+        N, V, _ = v.shape
+        out = torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_project(_lib.ptr(v), _lib.ptr(c), N, V, float(offset_z),
+                                               _lib.ptr(out), _lib.cur_stream(v.device)), "acfm_project")
+        ctx.save_for_backward(v, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, c = ctx.saved_tensors
+        N, V, _ = v.shape
+        g = _f32c(g)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_project_backward(_lib.ptr(v), _lib.ptr(c), _lib.ptr(g), N, V,
+                                                        _lib.ptr(gv), _lib.ptr(gc),
+                                                        _lib.cur_stream(v.device)),
+                       "acfm_project_backward")
+        return gv, gc, None
+
+
+def project(verts, cams, offset_z=0.0):
+    """[N,V,3] x [N,7] -> [N,V,3]; geom_utils.orthographic_proj_withz semantics."""
+    return _Project.apply(verts, cams, offset_z)
+
+
+# ------------------------------------------------------------------------------ silhouette
+class _SilRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces, cams, img_size, K, blur, sigma, offset_z):
+        _lib.require_gpu(verts, faces, cams)
+        v, c = _f32c(verts), _f32c(cams)
+        N, V, _ = v.shape
+        f = expand_faces(faces, N)
+        F, H = f.shape[1], int(img_size)
+        mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, K), dtype=torch.int64, device=v.device)
+        ws, nb = _workspace(N, V, F, v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_sil_forward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, float(blur), float(sigma),
+                float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(ws), nb,
+                _lib.cur_stream(v.device)), "acfm_sil_forward")
+        ctx.save_for_backward(v, f, c, mask, p2f)
+        ctx.cfg = (H, K, float(sigma), float(offset_z))
+        ctx.mark_non_differentiable(p2f)
+        return mask, p2f
+
+    @staticmethod
+    def backward(ctx, gmask, _gp2f):
+        v, f, c, mask, p2f = ctx.saved_tensors
+        H, K, sigma, offset_z = ctx.cfg
+        N, V, _ = v.shape
+        F = f.shape[1]
+        g = _f32c(gmask)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
+        ws, nb = _workspace(N, V, F, v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_sil_backward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(g), N,
+                V, F, H, K, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb,
+                _lib.cur_stream(v.device)), "acfm_sil_backward")
+        return gv, None, gc, None, None, None, None, None
+
+
+def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0):
+    """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,K] i64)."""
+    return _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z)
+
+
+# ------------------------------------------------------------------------------ hard raster
+def hard_raster(verts_proj, faces, img_size):
+    """OF_NeuralRenderer.forward: pre-projected verts -> pix_to_face [N,H,H,1] i64."""
+    _lib.require_gpu(verts_proj, faces)
+    v = _f32c(verts_proj)
+    N, V, _ = v.shape
+    f = expand_faces(faces, N)
+    F, H = f.shape[1], int(img_size)
+    p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+    ws, nb = _workspace(N, V, F, v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.lib().acfm_hard_raster(_lib.ptr(v), _lib.ptr(f), N, V, F, H, _lib.ptr(p2f),
+                                               _lib.ptr(ws), nb, _lib.cur_stream(v.device)),
+                   "acfm_hard_raster")
+    return p2f
+
+
+# ------------------------------------------------------------------------------ texture
+class _TexRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces, cams, atlas, img_size, sigma, gamma, offset_z):
+        _lib.require_gpu(verts, faces, cams, atlas)
+        v, c, a = _f32c(verts), _f32c(cams), _f32c(atlas)
+        N, V, _ = v.shape
+        f = expand_faces(faces, N)
+        F, H = f.shape[1], int(img_size)
+        if a.dim() != 5 or a.shape[0] != N or a.shape[1] != F or a.shape[2] != a.shape[3] or a.shape[4] != 3:
+            raise ValueError("atlas must be [N,F,R,R,3], got %s" % (tuple(a.shape),))
+        R = a.shape[2]
+        imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
+        sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+        tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
+        ws, nb = _workspace(N, V, F, v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_tex_forward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
+                float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
+                _lib.ptr(tidx), _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_tex_forward")
+        ctx.save_for_backward(tidx)
+        ctx.cfg = (N, F, H, R)
+        ctx.mark_non_differentiable(sil, p2f)
+        return imgs, sil, p2f
+
+    @staticmethod
+    def backward(ctx, gimgs, _gs, _gp):
+        (tidx,) = ctx.saved_tensors
+        N, F, H, R = ctx.cfg
+        ga = None
+        if ctx.needs_input_grad[3]:
+            g = _f32c(gimgs)
+            ga = torch.empty((N, F, R, R, 3), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.lib().acfm_tex_backward(_lib.ptr(g), _lib.ptr(tidx), N, F, H, R,
+                                                        _lib.ptr(ga), _lib.cur_stream(g.device)),
+                           "acfm_tex_backward")
+        # geometry / camera: integer texel lookup and K=1 blending send (numerically) no
+        # gradient -- |d rgb / d dist| <= 1e-6 |texel| from the delta=1e-10 term.
+        return None, None, None, ga, None, None, None, None
+
+
+def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
+    """Atlas-textured hard render: -> (imgs [N,3,H,H], sil [N,H,H], pix_to_face [N,H,H,1])."""
+    return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z)
+
+
+# ------------------------------------------------------------------------------ mask losses
+class _MaskLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, gt, edt):
+        _lib.require_gpu(mask, gt, edt)
+        m = _f32c(mask)
+        N = m.shape[0]
+        HW = m[0].numel()
+        g = _f32c(gt).reshape(N, HW) if gt is not None else None
+        e = _f32c(edt).reshape(N, HW) if edt is not None else None
+        out = torch.empty((N, 4), dtype=torch.float32, device=m.device)
+        with torch.cuda.device(m.device):
+            _lib.check(_lib.lib().acfm_mask_losses(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e), N, HW,
+                                                   _lib.ptr(out), _lib.cur_stream(m.device)),
+                       "acfm_mask_losses")
+        ctx.save_for_backward(m, g, e)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, g, e = ctx.saved_tensors
+        N = m.shape[0]
+        HW = m[0].numel()
+        go = _f32c(gout)
+        gm = torch.empty_like(m)
+        with torch.cuda.device(m.device):
+            _lib.check(_lib.lib().acfm_mask_losses_backward(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e),
+                                                            _lib.ptr(go), N, HW, _lib.ptr(gm),
+                                                            _lib.cur_stream(m.device)),
+                       "acfm_mask_losses_backward")
+        return gm, None, None
+
+
+def mask_losses(mask, gt=None, edt=None):
+    """One pass over the mask -> [N,4] = (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m)."""
+    return _MaskLosses.apply(mask, gt, edt)
+
+
+# ------------------------------------------------------------------------------ boundary loss
+def visible_vertices(pix_to_face, faces, nv):
+    """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv]."""
+    _lib.require_gpu(pix_to_face, faces)
+    p = pix_to_face.detach().to(torch.int64).contiguous()
+    N, K = p.shape[0], p.shape[-1]
+    HW = p[0].numel() // K
+    f = expand_faces(faces, N)
+    vis = torch.empty((N, nv), dtype=torch.uint8, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.lib().acfm_visible_vertices(_lib.ptr(p), _lib.ptr(f), N, nv, f.shape[1], HW, K,
+                                                    _lib.ptr(vis), _lib.cur_stream(p.device)),
+                   "acfm_visible_vertices")
+    return vis
+
+
+class _BdsLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts_xy, bds, vis):
+        _lib.require_gpu(verts_xy, bds, vis)
+        v, b = _f32c(verts_xy), _f32c(bds)
+        N, V, _ = v.shape
+        P = b.shape[1]
+        loss = torch.empty((N,), dtype=torch.float32, device=v.device)
+        arg = torch.empty((N, P), dtype=torch.int32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_bds_loss(_lib.ptr(v), _lib.ptr(b), _lib.ptr(vis.contiguous()), N,
+                                                V, P, _lib.ptr(loss), _lib.ptr(arg),
+                                                _lib.cur_stream(v.device)), "acfm_bds_loss")
+        ctx.save_for_backward(v, b, arg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        v, b, arg = ctx.saved_tensors
+        N, V, _ = v.shape
+        P = b.shape[1]
+        g = _f32c(gl)
+        gv = torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_bds_loss_backward(_lib.ptr(v), _lib.ptr(b), _lib.ptr(arg),
+                                                         _lib.ptr(g), N, V, P, _lib.ptr(gv),
+                                                         _lib.cur_stream(v.device)),
+                       "acfm_bds_loss_backward")
+        return gv, None, None
+
+
+def bds_loss_per_mesh(verts_xy, bds, vis):
+    """[N,V,2] x [N,P,3] x uint8 [N,V] -> [N] (sum over boundary points)."""
+    return _BdsLoss.apply(verts_xy, bds, vis)

@@ -1,0 +1,240 @@
+"""Headline benchmark: frames/s of differentiable render + backward, 642-vert bird template
+@256x256, 64 frames per GPU (BASELINE.json configs[1]), synthetic data resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of frames:
+deformation apply -> soft-silhouette render (K=20) -> fused L1/IoU/EDT losses -> boundary
+loss -> atlas-texture render + MSE -> backward to handle offsets, cameras, shared mean shape
+and atlas.  Frames are sharded over ranks (weak scaling: 64 frames per GPU); the only
+exchange is one RCCL all-reduce of the shared-shape gradient.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
+kernel, algorithmic bytes vs 8 TB/s HBM, durations from hipEvents on the launch stream) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--frames", type=int, default=64, help="frames per GPU")
+    p.add_argument("--img", type=int, default=256)
+    p.add_argument("--handles", type=int, default=16)
+    p.add_argument("--tex", type=int, default=1, help="include the atlas-texture render + loss")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-oracle time budget")
+    p.add_argument("--no-cpu", action="store_true")
+    return p.parse_args()
+
+
+def edt_and_boundaries(masks):
+    """set_input-style prep (multiframe/main.py:365-377, utils/image.py:94-146), done once on
+    the host before the timed region (out of the hot path)."""
+    from scipy.ndimage import binary_dilation, binary_erosion, distance_transform_edt
+    N, H, W = masks.shape
+    edts = np.stack([distance_transform_edt(1 - m) for m in masks]).astype(np.float32)
+    bds = []
+    for m in masks:
+        mb = m > 0.5
+        bd = binary_dilation(mb) & ~binary_erosion(mb)  # find_boundaries(mode='thick')
+        bds.append(np.transpose(bd.nonzero()))
+    P = min(1000, max(1, max(b.shape[0] for b in bds)))
+    out = np.zeros((N, P, 3), np.float32)
+    rng = np.random.default_rng(0)
+    for i, b in enumerate(bds):
+        if b.shape[0] > P:
+            b = b[rng.permutation(b.shape[0])[:P]]
+        k = b.shape[0]
+        out[i, :k, 0] = (b[:, 1] / W - 0.5) * 2  # (x, y) order, corner-based normalisation
+        out[i, :k, 1] = (b[:, 0] / H - 0.5) * 2
+        out[i, :k, 2] = 1
+    return edts[:, None], out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from acfm_video_3d_reconstruction_amd import _lib
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
+
+    N, H, Kh = a.frames, a.img, a.handles
+    m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
+    v_np, f_np = m["bird_v"], m["bird_f"]
+    V, F = v_np.shape[0], f_np.shape[0]
+    rng = np.random.default_rng(1000 + rank)
+    ext = float(np.abs(v_np).max())
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    mean_v = torch.tensor(v_np, device=dev)
+    faces = torch.tensor(f_np, device=dev)[None].repeat(N, 1, 1).contiguous()
+    lbs_logits = torch.tensor(fps_lbs_logits(v_np, Kh), device=dev)
+    solver = DeformSolver(mean_v, faces[0], lbs_logits)
+    delta0 = torch.tensor(rng.normal(0, 0.02, (N, Kh, 3)).astype(np.float32), device=dev)
+    cams0 = torch.tensor(make_cams(N, rng, extent=ext), device=dev)
+    renderer = NeuralRenderer(H)
+    with torch.no_grad():  # GT = own render of a differently perturbed pose, thresholded
+        gt_delta = torch.tensor(rng.normal(0, 0.03, (N, Kh, 3)).astype(np.float32), device=dev)
+        gt_cams = cams0.clone()
+        gt_cams[:, 1:3] += torch.tensor(rng.uniform(-0.03, 0.03, (N, 2)).astype(np.float32), device=dev)
+        gt_mask, _ = renderer(solver(gt_delta), faces, gt_cams)
+        gt_mask = (gt_mask > 0.5).float()
+    edt_np, bds_np = edt_and_boundaries(gt_mask.cpu().numpy())
+    edt = torch.tensor(edt_np, device=dev)
+    bds = torch.tensor(bds_np, device=dev)
+    imgs_gt = torch.tensor(rng.uniform(0, 1, (N, 3, H, H)).astype(np.float32), device=dev)
+    R = 6
+    atlas = torch.tensor(rng.uniform(0, 1, (N, F, R, R, 3)).astype(np.float32), device=dev, requires_grad=True)
+    delta = delta0.clone().requires_grad_(True)
+    cams = cams0.clone().requires_grad_(True)
+    mean_p = mean_v.clone().requires_grad_(True)
+    shared_grad = torch.zeros(V * 3, device=dev)
+
+    def step():
+        for t in (delta, cams, mean_p, atlas):
+            t.grad = None
+        pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
+        mask, p2f = renderer(pred_v, faces, cams)                        # a3
+        l1, iou, e = L.fused_silhouette_losses(mask, gt_mask, edt)       # a10, a11
+        proj = renderer.project_points(pred_v, cams)                     # a2
+        bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
+        total = (l1 + 0.1 * e + 0.1 * bdt).mean()
+        if a.tex:
+            tex, _, _ = renderer(pred_v.detach(), faces, cams, textures=atlas)   # a4
+            total = total + 0.5 * ((tex - imgs_gt) * gt_mask[:, None]).pow(2).mean()
+        total.backward()
+        if world > 1:  # the one exchange: shared mean-shape gradient
+            shared_grad.copy_(mean_p.grad.reshape(-1))
+            dist.all_reduce(shared_grad)
+        return total
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = 1e3 * dt / a.steps
+    value = world * N * a.steps / dt
+
+    # ---- per-kernel durations (hipEvents on the launch stream) over the same K steps
+    roof = None
+    kern = {}
+    lib = _lib.lib()
+    if rank == 0:
+        lib.acfm_prof_enable(1)
+    for _ in range(a.steps):  # every rank runs the same steps (the all-reduce is collective)
+        step()
+    fence()
+    if rank == 0:
+        ms = (ctypes.c_float * 16)()
+        cnt = (ctypes.c_int * 16)()
+        _lib.check(lib.acfm_prof_collect(ms, cnt, 16), "acfm_prof_collect")
+        lib.acfm_prof_enable(0)
+        for i in range(16):
+            if cnt[i]:
+                kern[lib.acfm_prof_name(i).decode()] = dict(avg_us=1e3 * ms[i] / cnt[i], launches=cnt[i],
+                                                            us_per_step=1e3 * ms[i] / a.steps)
+        dom = max(kern, key=lambda k: kern[k]["us_per_step"])
+        # ALGORITHMIC bytes per launch, fp32:
+        alg = {
+            # read verts 12V + cam 28 (+ faces 12F shared, once per batch); write mask 4H^2 + nearest face id 8H^2
+            "k_raster_fwd<K,soft>": N * (12 * H * H + 12 * V + 28) + 12 * F,
+            # read grad 4H^2 + mask 4H^2 + nearest id 8H^2; write grad_verts 12V + grad_cam 28
+            "k_sil_bwd": N * (16 * H * H + 12 * V + 28),
+            # read atlas 12FR^2 ; write image 12H^2 + sil 4H^2 + face id 8H^2
+            "k_raster_fwd<1,tex>": N * (24 * H * H + 12 * F * R * R + 12 * V + 28),
+            "k_tex_bwd": N * (12 * H * H + 4 * H * H + 12 * F * R * R),
+            "k_mask_losses": N * 12 * H * H, "k_mask_losses_bwd": N * 16 * H * H,
+        }
+        ab = alg.get(dom, 0)
+        ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
+        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        verts_np = solver(delta0).detach().cpu().numpy()
+        cams_np = cams0.cpu().numpy()
+        gmask = np.sign(np.random.default_rng(0).standard_normal((N, H, H))).astype(np.float32) / (H * H)
+        cores = len(os.sched_getaffinity(0))
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+
+        def cpu_frames(k):
+            t = time.perf_counter()
+            O.sil_render_backward(verts_np[:k], f_np, cams_np[:k], H, gmask[:k])
+            return time.perf_counter() - t
+        t1 = cpu_frames(1)
+        k = int(max(1, min(N, a.cpu_seconds / max(t1, 1e-3))))
+        tk = cpu_frames(k)
+        cpu = dict(value=round(k / tk, 3), unit="frames/s", cores=cores, kind="port",
+                   sample="oracle silhouette render K=20 + backward, %d frame(s) @%dx%d, OpenMP over rows" % (k, H, H))
+
+    if rank == 0:
+        out = {
+            "metric": "frames/s differentiable render+bwd, 642-vert mesh @256^2, batch=64",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CUB bird template (642 v / 1280 f), %d frames/GPU @%dx%d, deform apply + "
+                                   "soft silhouette K=20 + L1/IoU/EDT + boundary loss%s, fwd+bwd" %
+                                   (N, H, H, " + atlas texture render/MSE" if a.tex else ""),
+                       "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
+                       "sharding": "frames over ranks; all-reduce of shared mean-shape grad"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * acfm_hip.h -- C ABI of libacfm_hip.so, the MI355X (gfx950) implementation of ACFM's
+ * differentiable-render hot path.
+ *
+ * The reference (fkokkinos/acfm_video_3d_reconstruction) has no C ABI for this path: its
+ * boundary is Python (multiframe/nnutils/nmr.py, geom_utils.py, loss_utils.py) on top of
+ * the third-party PyTorch3D 0.3.0 extension `pytorch3d._C`.  Each entry point below names
+ * the reference interface it replaces; the Python operator surface that mirrors the
+ * reference's own signatures lives in acfm_video_3d_reconstruction_amd/nnutils/ and binds
+ * these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *     tensors are dense, row-major, fp32 / int64 / int32 as declared;
+ *   - the caller owns every buffer, outputs and workspace are pre-allocated
+ *     (no allocation, no host synchronisation inside: all entry points are stream-ordered
+ *     and hipGraph-capturable);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - return value: 0 = ok, ACFM_E_* otherwise (the Python layer raises RuntimeError);
+ *   - workspace sizes come from the matching *_workspace_bytes() query.
+ *
+ * Geometry conventions: cams [N,7] = (scale, tx, ty, qw, qx, qy, qz);
+ * rendered image row/column grow with +y_p/+x_p of orthographic_proj_withz; packed face id
+ * = n*F + f, -1 = empty; top-K ordered by ascending depth, ties -> smaller face id.
+ */
+#ifndef ACFM_HIP_H_
+#define ACFM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACFM_OK 0
+#define ACFM_E_BADARG 1   /* shape / parameter outside what the kernels support */
+#define ACFM_E_LAUNCH 2   /* hipLaunch or a preceding asynchronous error */
+#define ACFM_E_WORKSPACE 3 /* workspace too small */
+
+#define ACFM_MAX_K 32      /* faces_per_pixel upper bound */
+#define ACFM_MAX_FACES 65535 /* faces per mesh (16-bit local ids in the per-pixel lists) */
+
+/* library / device info ------------------------------------------------------------- */
+int acfm_version(void);              /* 1000*major + minor */
+const char* acfm_arch(void);         /* "gfx950" */
+
+/* ---- per-kernel timing (measurement aid, off by default) -------------------------------
+ * When enabled, every kernel launch inside the entry points is bracketed by hipEvents on
+ * the launch stream (ring of ACFM_PROF_RING pairs).  acfm_prof_collect synchronises those
+ * events and returns, per kernel id, the summed duration in ms and the launch count since
+ * the last collect/enable.  Not for use under hipGraph capture. */
+#define ACFM_PROF_SETUP 0
+#define ACFM_PROF_SIL_FWD 1
+#define ACFM_PROF_SIL_BWD 2
+#define ACFM_PROF_PROJ_BWD 3
+#define ACFM_PROF_TEX_FWD 4
+#define ACFM_PROF_HARD_FWD 5
+#define ACFM_PROF_TEX_BWD 6
+#define ACFM_PROF_MASK_LOSS 7
+#define ACFM_PROF_MASK_LOSS_BWD 8
+#define ACFM_PROF_VISIBLE 9
+#define ACFM_PROF_BDS 10
+#define ACFM_PROF_BDS_BWD 11
+#define ACFM_PROF_PROJECT 12
+#define ACFM_PROF_NKERNELS 16
+#define ACFM_PROF_RING 8192
+int acfm_prof_enable(int on);
+int acfm_prof_collect(float* ms_host, int* count_host, int n);
+const char* acfm_prof_name(int id);
+
+/* ---- projection ------------------------------------------------------------------
+ * replaces geom_utils.orthographic_proj_withz / orthographic_proj / quat_rotate
+ * (multiframe/nnutils/geom_utils.py:48-79, 134-152) and NeuralRenderer.project_points
+ * (multiframe/nnutils/nmr.py:127-129).
+ * verts [N,V,3], cams [N,7] -> proj [N,V,3] = (s*rot(q,X).xy + t, s*rot(q,X).z + offset_z) */
+int acfm_project(const float* verts, const float* cams, int N, int V, float offset_z,
+                 float* proj, void* stream);
+/* grad_proj [N,V,3] -> grad_verts [N,V,3] (may be NULL), grad_cams [N,7] (may be NULL) */
+int acfm_project_backward(const float* verts, const float* cams, const float* grad_proj, int N,
+                          int V, float* grad_verts, float* grad_cams, void* stream);
+
+/* ---- rasterisation workspace -------------------------------------------------------
+ * One workspace serves forward and backward of a render call of N meshes with V verts and
+ * F faces each (face records, NDC verts, per-mesh boxes, gradient scratch). */
+size_t acfm_raster_workspace_bytes(int N, int V, int F);
+
+/* ---- soft silhouette ---------------------------------------------------------------
+ * replaces NeuralRenderer.forward, mask branch (multiframe/nnutils/nmr.py:143-172):
+ * proj_fn -> y flip -> view (R=diag(-1,1,1), T=(0,0,2.732)) -> PyTorch3D
+ * rasterize_meshes(K, blur_radius, bin_size=None) -> sigmoid_alpha_blend(sigma).
+ *   verts_world [N,V,3] f32, faces [N,F,3] i64, cams [N,7] f32
+ *   -> mask [N,H,H] f32, pix_to_face [N,H,H,K] i64 (packed ids, ascending depth, -1 empty)
+ * `ws` is kept by the caller until acfm_sil_backward of the same call has run. */
+int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N,
+                     int V, int F, int H, int K, float blur_radius, float sigma, float offset_z,
+                     float* mask, int64_t* pix_to_face, void* ws, size_t ws_bytes, void* stream);
+
+/* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
+ * (dists path) + the projection chain.  grad_mask [N,H,H] -> grad_verts [N,V,3],
+ * grad_cams [N,7] (either may be NULL).  Recomputes the face setup from verts/cams, so
+ * `ws` does not have to survive from the forward call. */
+int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
+                      const float* mask, const int64_t* pix_to_face, const float* grad_mask,
+                      int N, int V, int F, int H, int K, float sigma, float offset_z,
+                      float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
+ * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are
+ * ALREADY projected by proj_fn; no y flip; view R=diag(-1,1,1), T=(0,0,2.732).
+ * -> pix_to_face [N,H,H,1] i64 */
+int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
+                     int64_t* pix_to_face, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- atlas-textured render -----------------------------------------------------------
+ * replaces NeuralRenderer.forward, texture branch with atlas=True
+ * (multiframe/nnutils/nmr.py:173-200): hard raster K=1, clip_barycentric_coords=True,
+ * TexturesAtlas.sample_textures, ambient-only SoftPhongShader, softmax_rgb_blend.
+ *   atlas [N,F,R,R,3] f32 -> imgs [N,3,H,H], sil [N,H,H], pix_to_face [N,H,H,1] i64,
+ *   texel_idx [N,H,H] i32 (linear texel index n*F*R*R + f*R*R + y*R + x, -1 empty;
+ *   saved for the backward pass). */
+int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
+                     const float* atlas, int N, int V, int F, int H, int R, float sigma,
+                     float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+                     int32_t* texel_idx, void* ws, size_t ws_bytes, void* stream);
+/* grad_imgs [N,3,H,H] -> grad_atlas [N,F,R,R,3] (zeroed here, then scatter-added).
+ * Integer texel indexing sends no gradient to geometry. */
+int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R,
+                      float* grad_atlas, void* stream);
+
+/* ---- fused silhouette losses ---------------------------------------------------------
+ * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False
+ * (multiframe/nnutils/loss_utils.py:18-32, 72-77, 245-253) in one pass over the mask:
+ *   out [N,4] = (mean|m-gt|, sum m*gt, sum (m+gt-m*gt), mean edt*m); gt / edt may be NULL. */
+int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW,
+                     float* out, void* stream);
+/* grad_mask [N,HW] = w_l1[n]*sign(m-gt)/HW + w_edt[n]*edt/HW + IoU term
+ * (w_inter[n]*gt + w_union[n]*(1-gt)); weights are per-mesh upstream gradients [N,4]. */
+int acfm_mask_losses_backward(const float* mask, const float* gt, const float* edt,
+                              const float* grad_out, int N, int HW, float* grad_mask,
+                              void* stream);
+
+/* ---- visibility + boundary loss ------------------------------------------------------
+ * visible-vertex bitmap shared by loss_utils.bds_loss (:214-224) and optical_flow_loss
+ * (:432-443): vis [N,V] u8 = 1 for every vertex of a face that appears in
+ * pix_to_face[..., 0].  pix_to_face has `K` ids per pixel (only slot 0 is read). */
+int acfm_visible_vertices(const int64_t* pix_to_face, const int64_t* faces, int N, int V, int F,
+                          int HW, int K, uint8_t* vis, void* stream);
+/* loss_utils.bds_loss (:204-237) given vis: for each boundary point the squared distance to
+ * the nearest visible projected vertex (1000 where none), times the point's valid flag,
+ * summed per mesh.  verts_xy [N,V,2], bds [N,P,3] -> loss [N], argmin [N,P] i32 (saved). */
+int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, int N, int V, int P,
+                  float* loss, int32_t* argmin, void* stream);
+int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_t* argmin,
+                           const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACFM_HIP_H_ */
