@@ -8,22 +8,30 @@
 // Design:
 //   * k_setup: one workgroup per mesh projects the V vertices into LDS (weak-perspective
 //     camera, y flip, view transform) and writes per-face records + blur-expanded boxes.
-//   * k_raster_fwd: one 256-thread workgroup per 16x16 pixel tile, each wave owns an 8x8
-//     pixel block (wave64-shaped, not 32-wide).  Faces are binned against the tile with
-//     wave ballots into an LDS candidate list (deterministic, face-ordered); every lane then
-//     walks the list (LDS broadcast reads) and keeps its top-K (depth, face) keys in an LDS
-//     column it alone owns (conflict-free [slot][lane] layout); a rank sort at the end
-//     gives the ascending-depth order PyTorch3D returns.
-//   * k_sil_bwd: per pixel, recompute the K distances from pix_to_face, accumulate the
-//     vertex gradients of the tile in LDS (ds_add_f32) and flush non-zeros with one global
-//     float atomic per touched vertex coordinate.
+//   * k_raster_fwd / k_sil_bwd share one skeleton: a 256-thread workgroup owns a 16x16 pixel
+//     tile, each wave64 an 8x8 pixel block.  Faces are binned against the tile with wave
+//     ballots into an LDS candidate list (deterministic, face-ordered, one barrier per 256
+//     faces); every lane then walks the list with LDS broadcast reads.
+//   * forward, K > 1: a lane appends its (depth, face) keys to ITS OWN K slots of the
+//     pix_to_face output (used as scratch, so no per-pixel LDS lists and 5 waves/SIMD instead
+//     of 2), multiplies the blend product on the fly, and finally sorts the keys in registers
+//     with a Batcher network and emits packed ids as 16-byte stores.  Pixels that saw more than
+//     K faces (replace-the-farthest path) redo their blend product over the K kept faces.
+//   * backward: the same walk; membership of a face in a pixel's top-K is `key <= kth[pixel]`
+//     (kth saved by the forward), gradients of a candidate are summed across the wave with DPP
+//     row shifts/broadcasts and ONE lane adds them to the tile's LDS vertex accumulator, which
+//     is flushed with one global float atomic per touched coordinate.
+//   * workgroups are dealt so that all tiles of a mesh run on one XCD (its face records stay
+//     in that XCD's L2).
 #include "acfm_common.h"
+#include "acfm_sortnet.h"
 
 namespace acfm {
 
 constexpr int TILE = 16;      // pixels per tile side (PyTorch3D's auto bin size at 128/256)
 constexpr int TPB = 256;      // threads per workgroup = TILE*TILE
-constexpr int CAP = 256;      // LDS candidate-list capacity (flushed in rounds when exceeded)
+constexpr int CAP = 512;      // LDS candidate-list capacity (walked early when it could overflow)
+constexpr unsigned long long KEY_NONE = ~0ull;
 
 // ------------------------------------------------------------------------------- setup
 // mode 0: verts are world coordinates -> project with cams, flip y   (nmr.py:145-149)
@@ -91,166 +99,211 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   }
 }
 
+// ------------------------------------------------------------------------------- tile skeleton
+struct Tile {
+  int n, tid, wv, lane, yi, xi;
+  bool valid;
+  float xf, yf;
+  size_t pix;
+  float t_xmin, t_xmax, t_ymin, t_ymax;
+};
+
+// Workgroup -> (mesh, tile).  Workgroups are dealt round-robin over the 8 XCDs, so with
+// N % 8 == 0 mesh n is pinned to the blocks b with b % 8 == n % 8 (one XCD's L2 then holds the
+// records of the meshes it renders).  Pure speed: any mapping gives the same result.
+__device__ __forceinline__ Tile make_tile(int N, int H) {
+  Tile t;
+  const int tiles = (H + TILE - 1) / TILE;
+  const int tt = tiles * tiles;
+  const unsigned b = blockIdx.x;
+  int n, tl;
+  if ((N & 7) == 0) {
+    const unsigned xcd = b & 7u, j = b >> 3;
+    n = (int)(j / tt) * 8 + (int)xcd;
+    tl = (int)(j % tt);
+  } else {
+    n = (int)(b / tt);
+    tl = (int)(b % tt);
+  }
+  t.n = n;
+  t.tid = threadIdx.x; t.wv = t.tid >> 6; t.lane = t.tid & 63;
+  const int ty = tl / tiles, tx = tl % tiles;
+  t.yi = ty * TILE + (t.wv >> 1) * 8 + (t.lane >> 3);
+  t.xi = tx * TILE + (t.wv & 1) * 8 + (t.lane & 7);
+  t.valid = (t.yi < H) && (t.xi < H);
+  t.yf = pix_to_ndc(H - 1 - t.yi, H);
+  t.xf = pix_to_ndc(H - 1 - t.xi, H);
+  t.pix = ((size_t)n * H + t.yi) * H + t.xi;
+  // tile extent in NDC (pixel centres; x/y decrease with the pixel index)
+  t.t_xmax = pix_to_ndc(H - 1 - tx * TILE, H); t.t_xmin = pix_to_ndc(H - 1 - (tx * TILE + TILE - 1), H);
+  t.t_ymax = pix_to_ndc(H - 1 - ty * TILE, H); t.t_ymin = pix_to_ndc(H - 1 - (ty * TILE + TILE - 1), H);
+  return t;
+}
+
+struct CandList {
+  float4 box[CAP], a[CAP], b[CAP];
+  float2 c[CAP];    // (z2, area)
+  int fid[CAP];
+  int wcnt[2][4];
+};
+
+// Bins the F faces of mesh t.n against the tile and calls walk(count) (all threads, uniform)
+// whenever the LDS list is complete or could overflow.  WITH_VIDX also stages the vertex ids.
+template <bool WITH_VIDX, class Walk>
+__device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, CandList& L,
+                                             int4* s_vidx, Walk&& walk) {
+  const float4 mb = ws.mbox[t.n];
+  if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
+  int list_n = 0;
+  const int rounds = (F + TPB - 1) / TPB;
+  for (int r = 0; r < rounds; ++r) {
+    const int f = r * TPB + t.tid;
+    bool pass = false;
+    float4 b = make_float4(0, 0, 0, 0);
+    if (f < F) {
+      b = ws.box[(size_t)t.n * F + f];
+      pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (t.lane == 0) L.wcnt[r & 1][t.wv] = __popcll(bal);
+    __syncthreads();
+    int off = list_n, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = L.wcnt[r & 1][i];
+      if (i < t.wv) off += c;
+      tot += c;
+    }
+    if (pass) {
+      const int pos = off + __popcll(bal & ((1ull << t.lane) - 1ull));
+      const size_t o = (size_t)t.n * F + f;
+      L.box[pos] = b;
+      L.a[pos] = ws.recA[o];
+      L.b[pos] = ws.recB[o];
+      const float4 c4 = ws.recC[o];
+      L.c[pos] = make_float2(c4.x, c4.y);
+      L.fid[pos] = f;
+      if (WITH_VIDX) s_vidx[pos] = ws.vidx[o];
+    }
+    list_n += tot;
+    const bool last = (r == rounds - 1);
+    if (list_n > CAP - TPB || last) {
+      __syncthreads();
+      if (list_n > 0) walk(list_n);
+      list_n = 0;
+      if (!last) __syncthreads();
+    }
+  }
+}
+
+struct Hit { float pz, sd, c0, c1; };
+
+// One pixel against one face, in the oracle's operation order (oracle_rasterize).
+template <bool CLIP>
+__device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, const float4& B,
+                                          float z2, float area, float blur, Hit& h) {
+  const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
+  const float z0 = B.z, z1 = B.w;
+  const float denom = area + ACFM_K_EPS;
+  const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / denom;
+  const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / denom;
+  const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / denom;
+  float c0 = w0, c1 = w1, c2 = w2;
+  if (CLIP) {
+    c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
+    c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
+    c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
+  }
+  const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+  if (pz < 0.0f) return false;
+  const float d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
+  const float d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
+  const float d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
+  const float d = fminf(fminf(d01, d02), d12);
+  const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  if (!inside && d >= blur) return false;
+  h.pz = pz; h.sd = inside ? -d : d; h.c0 = c0; h.c1 = c1;
+  return true;
+}
+
+// (depth, face) key: pz >= 0 so its bit pattern orders like the float; +0.0f folds -0.0 into
+// +0.0.  Smaller face id wins a depth tie.
+__device__ __forceinline__ unsigned long long make_key(float pz, int fid) {
+  return ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)fid;
+}
+
 // ------------------------------------------------------------------------------- forward
 struct FwdOut {
-  float* mask;          // SOFT: [N,H,H]
-  int64_t* p2f;         // [N,H,H,K]
+  float* mask;               // soft: [N,H,H]
+  int64_t* p2f;              // [N,H,H,K]
+  unsigned long long* kth;   // soft, optional: [N,H,H] largest kept key if K faces kept, else ~0
+  uint8_t* vis;              // optional: [N,V] vertices of every nearest face
+  int V;
   // texture branch (TEX)
-  const float* atlas;   // [N,F,R,R,3]
-  float* imgs;          // [N,3,H,H]
-  float* sil;           // [N,H,H]
-  int32_t* tidx;        // [N,H,H]
+  const float* atlas;        // [N,F,R,R,3]
+  float* imgs;               // [N,3,H,H]
+  float* sil;                // [N,H,H]
+  int32_t* tidx;             // [N,H,H]
   int R;
   float gamma;
 };
 
-template <int K>
-struct PixList {
-  // per-thread top-K list in LDS, [slot][thread] so a wave's accesses never conflict
-  unsigned long long key[K][TPB];
-  float sd[K][TPB];
-};
+template <int K> struct SortNet;
+#define ACFM_CE(i, j) { const unsigned long long a_ = k[i], b_ = k[j]; const bool s_ = a_ > b_; \
+                        k[i] = s_ ? b_ : a_; k[j] = s_ ? a_ : b_; }
+#define ACFM_DEF_SORT(KK)                                                             \
+  template <> struct SortNet<KK> {                                                    \
+    static __device__ __forceinline__ void run(unsigned long long (&k)[KK]) {         \
+      ACFM_SORTNET_##KK(ACFM_CE)                                                      \
+    }                                                                                 \
+  };
+ACFM_DEF_SORT(2) ACFM_DEF_SORT(4) ACFM_DEF_SORT(8) ACFM_DEF_SORT(10) ACFM_DEF_SORT(20) ACFM_DEF_SORT(32)
+
+__device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
+  const int4 vi = ws.vidx[(size_t)n * F + f];
+  uint8_t* v = out.vis + (size_t)n * out.V;
+  v[vi.x] = 1; v[vi.y] = 1; v[vi.z] = 1;
+}
 
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int F, int H, float blur, float sigma,
-                                                    FwdOut out) {
-  __shared__ float4 s_box[CAP], s_a[CAP], s_b[CAP];
-  __shared__ float2 s_c[CAP];
-  __shared__ int s_fid[CAP];
-  __shared__ int s_wcnt[4];
-  constexpr int KL = (K > 1) ? K : 1;
-  __shared__ PixList<(K > 1) ? KL : 1> s_list;  // unused (1 slot) when K == 1
-
-  const int n = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int tiles = (H + TILE - 1) / TILE;
-  const int ty = blockIdx.x / tiles, tx = blockIdx.x % tiles;
-  const int yi = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
-  const int xi = tx * TILE + (wv & 1) * 8 + (lane & 7);
-  const bool valid = (yi < H) && (xi < H);
-  const float yf = pix_to_ndc(H - 1 - yi, H);
-  const float xf = pix_to_ndc(H - 1 - xi, H);
-  const size_t pix = ((size_t)n * H + yi) * H + xi;
-
-  // tile extent in NDC (pixel centres; x/y decrease with the pixel index)
-  const float t_xmax = pix_to_ndc(H - 1 - tx * TILE, H), t_xmin = pix_to_ndc(H - 1 - (tx * TILE + TILE - 1), H);
-  const float t_ymax = pix_to_ndc(H - 1 - ty * TILE, H), t_ymin = pix_to_ndc(H - 1 - (ty * TILE + TILE - 1), H);
-
-  int cnt = 0;                              // entries in this pixel's list
-  unsigned long long maxkey = 0; int maxslot = 0;   // valid when cnt == K (K > 1)
-  unsigned long long bestkey = ~0ull; float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f;  // K == 1
-
-  const float4 mb = ws.mbox[n];
-  const bool tile_hit = !(t_xmin > mb.y || t_xmax < mb.x || t_ymin > mb.w || t_ymax < mb.z);
-  if (tile_hit) {
-    int list_n = 0;
-    for (int base = 0; base < F; base += TPB) {
-      const int f = base + tid;
-      bool pass = false;
-      if (f < F) {
-        const float4 b = ws.box[(size_t)n * F + f];
-        pass = !(t_xmin > b.y || t_xmax < b.x || t_ymin > b.w || t_ymax < b.z);
-      }
-      const unsigned long long bal = __ballot(pass);
-      if (lane == 0) s_wcnt[wv] = __popcll(bal);
-      __syncthreads();
-      int off = list_n, tot = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = s_wcnt[i];
-        if (i < wv) off += c;
-        tot += c;
-      }
-      if (pass) {
-        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-        const size_t o = (size_t)n * F + f;
-        s_box[pos] = ws.box[o];
-        s_a[pos] = ws.recA[o];
-        s_b[pos] = ws.recB[o];
-        const float4 c4 = ws.recC[o];
-        s_c[pos] = make_float2(c4.x, c4.y);
-        s_fid[pos] = f;
-      }
-      list_n += tot;
-      __syncthreads();
-      const bool last = (base + TPB >= F);
-      if (list_n > CAP - TPB || last) {
-        // ---- every pixel walks the candidate list
-        if (valid) {
-          for (int c = 0; c < list_n; ++c) {
-            const float4 bx = s_box[c];
-            if (xf > bx.y || xf < bx.x || yf > bx.w || yf < bx.z) continue;
-            const float4 A = s_a[c], B = s_b[c];
-            const float2 C = s_c[c];
-            const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
-            const float z0 = B.z, z1 = B.w, z2 = C.x;
-            const float denom = C.y + ACFM_K_EPS;
-            const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / denom;
-            const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / denom;
-            const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / denom;
-            float c0 = w0, c1 = w1, c2 = w2;
-            if (CLIP) {
-              c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
-              c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
-              c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
-              const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-              c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
-            }
-            const float pz = c0 * z0 + c1 * z1 + c2 * z2;
-            if (pz < 0.0f) continue;
-            const float d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-            const float d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
-            const float d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
-            const float d = fminf(fminf(d01, d02), d12);
-            const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-            if (!inside && d >= blur) continue;
-            const float sd = inside ? -d : d;
-            // (depth, face) key: pz >= 0 so its bit pattern orders like the float; +0.0f
-            // folds -0.0 into +0.0.  Smaller face id wins a depth tie.
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)s_fid[c];
-            if (K == 1) {
-              if (key < bestkey) { bestkey = key; bestsd = sd; bestb0 = c0; bestb1 = c1; }
-            } else {
-              bool rescan = false;
-              if (cnt < K) {
-                s_list.key[cnt][tid] = key; s_list.sd[cnt][tid] = sd;
-                cnt++;
-                rescan = (cnt == K);
-              } else if (key < maxkey) {
-                s_list.key[maxslot][tid] = key; s_list.sd[maxslot][tid] = sd;
-                rescan = true;
-              }
-              if (rescan) {
-                maxkey = 0; maxslot = 0;
-                for (int k = 0; k < KL; ++k) {
-                  const unsigned long long kk = s_list.key[k][tid];
-                  if (kk >= maxkey) { maxkey = kk; maxslot = k; }
-                }
-              }
-            }
-          }
-        }
-        list_n = 0;
-        __syncthreads();
-      }
-    }
-  }
-
-  if (!valid) return;
+__global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+                                                    float sigma, FwdOut out) {
+  __shared__ CandList L;
+  const Tile t = make_tile(N, H);
+  const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
-  if (K == 1) {
-    const bool hit = (bestkey != ~0ull);
+
+  if constexpr (K == 1) {
+    unsigned long long bestkey = KEY_NONE;
+    float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f;
+    bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
+      if (!t.valid) return;
+      for (int c = 0; c < list_n; ++c) {
+        const float4 bx = L.box[c];
+        if (t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z) continue;
+        const float2 C = L.c[c];
+        Hit h;
+        if (!test_face<CLIP>(t.xf, t.yf, L.a[c], L.b[c], C.x, C.y, blur, h)) continue;
+        const unsigned long long key = make_key(h.pz, L.fid[c]);
+        if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; }
+      }
+    });
+    if (!t.valid) return;
+    const bool hit = (bestkey != KEY_NONE);
     const int f = (int)(bestkey & 0xffffffffu);
-    out.p2f[pix] = hit ? fbase + f : (int64_t)-1;
+    out.p2f[t.pix] = hit ? fbase + f : (int64_t)-1;
+    if (out.vis && hit) mark_visible(ws, out, n, F, f);
     if (TEX) {
       // TexturesAtlas.sample_textures + ambient-only Phong + softmax_rgb_blend, K = 1
       // (oracle_atlas_shade is the line-by-line spec)
       const size_t HW = (size_t)H * H;
-      float* img = out.imgs + (size_t)n * 3 * HW + (size_t)yi * H + xi;
+      float* img = out.imgs + (size_t)n * 3 * HW + (size_t)t.yi * H + t.xi;
       if (!hit) {
         img[0] = 0.f; img[HW] = 0.f; img[2 * HW] = 0.f;
-        out.sil[pix] = 0.f;
-        out.tidx[pix] = -1;
+        out.sil[t.pix] = 0.f;
+        out.tidx[t.pix] = -1;
       } else {
         const int R = out.R;
         const float zb = __uint_as_float((unsigned)(bestkey >> 32));
@@ -270,28 +323,109 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int F, int H, f
         img[0] = (wnum * tx3[0] + delta * 0.0f) / den;
         img[HW] = (wnum * tx3[1] + delta * 0.0f) / den;
         img[2 * HW] = (wnum * tx3[2] + delta * 0.0f) / den;
-        out.sil[pix] = 1.0f - (1.0f - prob);
-        out.tidx[pix] = (int32_t)ti;
+        out.sil[t.pix] = 1.0f - (1.0f - prob);
+        out.tidx[t.pix] = (int32_t)ti;
       }
     }
   } else {
-    // rank sort of the (<= K) kept keys, blend in list order
-    int64_t* o = out.p2f + pix * K;
+    // this pixel's K output slots double as the key list while the tile is walked
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(out.p2f) + t.pix * K;
+    int cnt = 0;
+    bool overflow = false;               // a face was dropped/replaced: alpha must be redone
+    unsigned long long maxkey = 0; int maxslot = 0;   // valid when cnt == K
     float alpha = 1.0f;
-    for (int i = 0; i < cnt; ++i) {
-      const unsigned long long ki = s_list.key[i][tid];
-      int rank = 0;
-      for (int j = 0; j < cnt; ++j) rank += (s_list.key[j][tid] < ki) ? 1 : 0;
-      o[rank] = fbase + (int64_t)(ki & 0xffffffffu);
-      const float prob = sigmoid_neg(s_list.sd[i][tid], sigma);
-      alpha = alpha * (1.0f - prob);
+    bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
+      if (!t.valid) return;
+      for (int c = 0; c < list_n; ++c) {
+        const float4 bx = L.box[c];
+        if (t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z) continue;
+        const float2 C = L.c[c];
+        Hit h;
+        if (!test_face<CLIP>(t.xf, t.yf, L.a[c], L.b[c], C.x, C.y, blur, h)) continue;
+        const unsigned long long key = make_key(h.pz, L.fid[c]);
+        bool rescan = false;
+        if (cnt < K) {
+          slots[cnt] = key;
+          alpha = alpha * (1.0f - sigmoid_neg(h.sd, sigma));
+          cnt++;
+          rescan = (cnt == K);
+        } else {
+          overflow = true;
+          if (key < maxkey) { slots[maxslot] = key; rescan = true; }
+        }
+        if (rescan) {  // rare: find the farthest kept face again
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          maxkey = 0; maxslot = 0;
+          for (int k = 0; k < K; ++k) {
+            const unsigned long long kk = slots[k];
+            if (kk >= maxkey) { maxkey = kk; maxslot = k; }
+          }
+        }
+      }
+    });
+    if (!t.valid) return;
+    longlong2* o2 = reinterpret_cast<longlong2*>(out.p2f + t.pix * K);  // K even -> 16-B aligned
+    if (cnt == 0) {
+#pragma unroll
+      for (int k2 = 0; k2 < K / 2; ++k2) o2[k2] = make_longlong2(-1, -1);
+      out.mask[t.pix] = 0.0f;
+      if (out.kth) out.kth[t.pix] = KEY_NONE;
+      return;
     }
-    for (int k = cnt; k < K; ++k) o[k] = -1;
-    out.mask[pix] = 1.0f - alpha;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own appends have landed before the read-back
+    unsigned long long key[K];
+#pragma unroll
+    for (int k2 = 0; k2 < K / 2; ++k2) {
+      const longlong2 v = o2[k2];
+      key[2 * k2] = (2 * k2 < cnt) ? (unsigned long long)v.x : KEY_NONE;
+      key[2 * k2 + 1] = (2 * k2 + 1 < cnt) ? (unsigned long long)v.y : KEY_NONE;
+    }
+    SortNet<K>::run(key);
+    if (overflow) {
+      // blend over exactly the K kept faces (ascending depth), distances recomputed
+      alpha = 1.0f;
+      for (int k = 0; k < K; ++k) {
+        // static register index: walk a copy of the sorted keys through slot 0
+        unsigned long long kk = key[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j) kk = (j == k) ? key[j] : kk;
+        const size_t o = (size_t)n * F + (size_t)(kk & 0xffffffffu);
+        const float4 C = ws.recC[o];
+        Hit h;
+        h.sd = 0.f;
+        test_face<CLIP>(t.xf, t.yf, ws.recA[o], ws.recB[o], C.x, C.y, blur, h);
+        alpha = alpha * (1.0f - sigmoid_neg(h.sd, sigma));
+      }
+    }
+    out.mask[t.pix] = 1.0f - alpha;
+    if (out.kth) out.kth[t.pix] = (cnt == K) ? key[K - 1] : KEY_NONE;
+    if (out.vis) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
+#pragma unroll
+    for (int k2 = 0; k2 < K / 2; ++k2) {
+      longlong2 v;
+      v.x = (key[2 * k2] != KEY_NONE) ? fbase + (long long)(key[2 * k2] & 0xffffffffu) : (long long)-1;
+      v.y = (key[2 * k2 + 1] != KEY_NONE) ? fbase + (long long)(key[2 * k2 + 1] & 0xffffffffu) : (long long)-1;
+      o2[k2] = v;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------- backward
+// wave64 sum on GFX9 DPP: row shifts inside each row of 16, then row broadcasts; the total
+// lands in lane 63 and is returned wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define ACFM_DPP_ADD(ctrl, rmask) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+  ACFM_DPP_ADD(0x111, 0xf);  // row_shr:1
+  ACFM_DPP_ADD(0x112, 0xf);  // row_shr:2
+  ACFM_DPP_ADD(0x114, 0xf);  // row_shr:4
+  ACFM_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row total
+  ACFM_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  ACFM_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef ACFM_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // PointLineDistanceBackward with the clamped t held constant
 __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax, float ay, float bx,
                                                     float by, float g, float& gax, float& gay,
@@ -312,73 +446,80 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
 }
 
 __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
-                                                 const int64_t* __restrict__ p2f,
-                                                 const float* __restrict__ grad_mask, int V, int F,
-                                                 int H, int K, float sigma) {
+                                                 const unsigned long long* __restrict__ kth,
+                                                 const float* __restrict__ grad_mask, int N, int V,
+                                                 int F, int H, float blur, float sigma) {
+  __shared__ CandList L;
+  __shared__ int4 s_vidx[CAP];
   extern __shared__ float s_g[];  // [V][2] tile-local vertex gradient
-  const int n = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int tiles = (H + TILE - 1) / TILE;
-  const int ty = blockIdx.x / tiles, tx = blockIdx.x % tiles;
-  const int yi = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
-  const int xi = tx * TILE + (wv & 1) * 8 + (lane & 7);
-  const bool valid = (yi < H) && (xi < H);
-  const size_t pix = ((size_t)n * H + yi) * H + xi;
+  const Tile t = make_tile(N, H);
 
-  // skip tiles with nothing to do before touching LDS
+  // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
+  // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
-  bool work = false;
-  if (valid) {
-    const float g = grad_mask[pix], m = mask[pix];
-    // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form)
-    coef = -g * (1.0f - m) / sigma;
-    work = (coef != 0.0f) && (p2f[pix * K] >= 0);
-  }
-  if (!__syncthreads_or(work)) return;
-
-  for (int i = tid; i < 2 * V; i += TPB) s_g[i] = 0.f;
-  __syncthreads();
-
-  if (work) {
-    const float yf = pix_to_ndc(H - 1 - yi, H);
-    const float xf = pix_to_ndc(H - 1 - xi, H);
-    const int64_t fbase = (int64_t)n * F;
-    for (int k = 0; k < K; ++k) {
-      const int64_t fp = p2f[pix * K + k];
-      if (fp < 0) break;
-      int f = (int)(fp - fbase);
-      f = min(max(f, 0), F - 1);
-      const size_t o = (size_t)n * F + f;
-      const float4 A = ws.recA[o], B = ws.recB[o], C = ws.recC[o];
-      const int4 vi = ws.vidx[o];
-      const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
-      const float denom = C.y + ACFM_K_EPS;
-      const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / denom;
-      const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / denom;
-      const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / denom;
-      const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-      const float d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-      const float d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
-      const float d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
-      const float d = fminf(fminf(d01, d02), d12);
-      const float sd = inside ? -d : d;
-      const float gs = coef * sigmoid_neg(sd, sigma);  // dL / d sd
-      const float gd = inside ? -gs : gs;              // dL / d d
-      float gax, gay, gbx, gby;
-      int ia, ib;
-      if (d01 <= d02 && d01 <= d12) {
-        point_line_dist_bwd(xf, yf, x0, y0, x1, y1, gd, gax, gay, gbx, gby); ia = vi.x; ib = vi.y;
-      } else if (d02 <= d01 && d02 <= d12) {
-        point_line_dist_bwd(xf, yf, x0, y0, x2, y2, gd, gax, gay, gbx, gby); ia = vi.x; ib = vi.z;
-      } else {
-        point_line_dist_bwd(xf, yf, x1, y1, x2, y2, gd, gax, gay, gbx, gby); ia = vi.y; ib = vi.z;
-      }
-      atomicAdd(&s_g[2 * ia], gax); atomicAdd(&s_g[2 * ia + 1], gay);
-      atomicAdd(&s_g[2 * ib], gbx); atomicAdd(&s_g[2 * ib + 1], gby);
+  unsigned long long kthkey = KEY_NONE;
+  if (t.valid) {
+    const float m = mask[t.pix];
+    if (m != 0.0f) {
+      coef = -grad_mask[t.pix] * (1.0f - m) / sigma;
+      kthkey = kth[t.pix];
     }
   }
+  const bool work = (coef != 0.0f);
+  if (!__syncthreads_or(work)) return;
+
+  for (int i = t.tid; i < 2 * V; i += TPB) s_g[i] = 0.f;
+  // (the first barrier inside bin_and_walk orders this before any accumulation)
+
+  bin_and_walk<true>(ws, t, F, L, s_vidx, [&](int list_n) {
+    if (__ballot(work) == 0ull) return;  // nothing to do in this 8x8 block
+    for (int c = 0; c < list_n; ++c) {
+      const float4 bx = L.box[c];
+      bool member = work && !(t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z);
+      if (__ballot(member) == 0ull) continue;
+      const float4 A = L.a[c], B = L.b[c];
+      const float2 C = L.c[c];
+      Hit h;
+      h.pz = 0.f; h.sd = 0.f;
+      member = member && test_face<false>(t.xf, t.yf, A, B, C.x, C.y, blur, h);
+      member = member && (make_key(h.pz, L.fid[c]) <= kthkey);
+      if (__ballot(member) == 0ull) continue;
+      float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
+      if (member) {
+        const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
+        // inside <=> sd < 0: an inside pixel lies on no edge, so d > 0 and sd = -d < 0
+        const bool inside = h.sd < 0.0f;
+        const float gs = coef * sigmoid_neg(h.sd, sigma);   // dL / d sd
+        const float gd = inside ? -gs : gs;                 // sd = inside ? -d : d
+        const float d01 = point_line_dist(t.xf, t.yf, x0, y0, x1, y1);
+        const float d02 = point_line_dist(t.xf, t.yf, x0, y0, x2, y2);
+        const float d12 = point_line_dist(t.xf, t.yf, x1, y1, x2, y2);
+        float ax_, ay_, bx_, by_;
+        if (d01 <= d02 && d01 <= d12) {
+          point_line_dist_bwd(t.xf, t.yf, x0, y0, x1, y1, gd, ax_, ay_, bx_, by_);
+          g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_;
+        } else if (d02 <= d01 && d02 <= d12) {
+          point_line_dist_bwd(t.xf, t.yf, x0, y0, x2, y2, gd, ax_, ay_, bx_, by_);
+          g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_;
+        } else {
+          point_line_dist_bwd(t.xf, t.yf, x1, y1, x2, y2, gd, ax_, ay_, bx_, by_);
+          g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_;
+        }
+      }
+      g0x = wave_sum_dpp(g0x); g0y = wave_sum_dpp(g0y);
+      g1x = wave_sum_dpp(g1x); g1y = wave_sum_dpp(g1y);
+      g2x = wave_sum_dpp(g2x); g2y = wave_sum_dpp(g2y);
+      if (t.lane == 0) {
+        const int4 vi = s_vidx[c];
+        atomicAdd(&s_g[2 * vi.x], g0x); atomicAdd(&s_g[2 * vi.x + 1], g0y);
+        atomicAdd(&s_g[2 * vi.y], g1x); atomicAdd(&s_g[2 * vi.y + 1], g1y);
+        atomicAdd(&s_g[2 * vi.z], g2x); atomicAdd(&s_g[2 * vi.z + 1], g2y);
+      }
+    }
+  });
   __syncthreads();
-  float* gout = ws.grad_ndc + (size_t)n * V * 2;
-  for (int i = tid; i < 2 * V; i += TPB) {
+  float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
+  for (int i = t.tid; i < 2 * V; i += TPB) {
     const float v = s_g[i];
     if (v != 0.0f) atomicAdd(&gout[i], v);
   }
@@ -514,12 +655,16 @@ static bool bad_dims(int N, int V, int F, int H) {
          (size_t)N * F > 0x7fffffffull;
 }
 
+static unsigned tile_grid(int N, int H) {
+  const int tiles = (H + TILE - 1) / TILE;
+  return (unsigned)((size_t)tiles * tiles * N);
+}
+
 template <int K>
 static int launch_sil_fwd(const RasterWs& ws, int N, int F, int H, float blur, float sigma,
                           const FwdOut& out, hipStream_t st) {
-  const int tiles = (H + TILE - 1) / TILE;
   ProfScope ps(ACFM_PROF_SIL_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tiles * tiles, N), dim3(TPB), 0, st, ws, F,
+  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F,
                      H, blur, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -531,7 +676,7 @@ using namespace acfm;
 
 extern "C" {
 
-int acfm_version(void) { return 1000; }
+int acfm_version(void) { return 1001; }
 const char* acfm_arch(void) { return "gfx950"; }
 
 int acfm_prof_enable(int on) {
@@ -595,7 +740,8 @@ int acfm_project_backward(const float* verts, const float* cams, const float* gr
 
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
                      int F, int H, int K, float blur_radius, float sigma, float offset_z, float* mask,
-                     int64_t* pix_to_face, void* wsp, size_t ws_bytes, void* stream) {
+                     int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp, size_t ws_bytes,
+                     void* stream) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f)
     return ACFM_E_BADARG;
@@ -604,9 +750,13 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, blur_radius, ws, st);
   if (rc) return rc;
+  if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.mask = mask;
   out.p2f = pix_to_face;
+  out.kth = reinterpret_cast<unsigned long long*>(kth);
+  out.vis = vis;
+  out.V = V;
   switch (K) {
     case 20: return launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, st);
     case 10: return launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, st);
@@ -619,26 +769,25 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
 }
 
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
-                      const float* mask, const int64_t* pix_to_face, const float* grad_mask, int N,
-                      int V, int F, int H, int K, float sigma, float offset_z, float* grad_verts,
+                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                      int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
                       float* grad_cams, void* wsp, size_t ws_bytes, void* stream) {
-  if (!verts_world || !faces || !cams || !mask || !pix_to_face || !grad_mask || !wsp)
-    return ACFM_E_BADARG;
-  if (bad_dims(N, V, F, H) || K < 1 || K > ACFM_MAX_K || !(sigma > 0.f)) return ACFM_E_BADARG;
+  if (!verts_world || !faces || !cams || !mask || !kth || !grad_mask || !wsp) return ACFM_E_BADARG;
+  if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, 0.f, ws, st);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, blur_radius, ws, st);
   if (rc) return rc;
   if (hipMemsetAsync(ws.grad_ndc, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
     return ACFM_E_LAUNCH;
   const size_t lds = sizeof(float) * 2 * (size_t)V;
-  if (lds > 150 * 1024) return ACFM_E_BADARG;
-  const int tiles = (H + TILE - 1) / TILE;
+  if (lds > 96 * 1024) return ACFM_E_BADARG;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tiles * tiles, N), dim3(TPB), lds, st, ws, mask, pix_to_face,
-                       grad_mask, V, F, H, K, sigma);
+    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H)), dim3(TPB), lds, st, ws, mask,
+                       reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
+                       blur_radius, sigma);
   }
   ACFM_CHECK_LAUNCH();
   if (grad_verts || grad_cams) {
@@ -651,19 +800,21 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
 }
 
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
-                     int64_t* pix_to_face, void* wsp, size_t ws_bytes, void* stream) {
+                     int64_t* pix_to_face, uint8_t* vis, void* wsp, size_t ws_bytes, void* stream) {
   if (!verts_proj || !faces || !pix_to_face || !wsp || bad_dims(N, V, F, H)) return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, 0.f, 1, 0.f, ws, st);
   if (rc) return rc;
+  if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.p2f = pix_to_face;
-  const int tiles = (H + TILE - 1) / TILE;
+  out.vis = vis;
+  out.V = V;
   ProfScope ps(ACFM_PROF_HARD_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tiles * tiles, N), dim3(TPB), 0, st, ws, F, H,
-                     0.f, 1e-4f, out);
+  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F,
+                     H, 0.f, 1e-4f, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -684,9 +835,8 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   FwdOut out = {};
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
-  const int tiles = (H + TILE - 1) / TILE;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tiles * tiles, N), dim3(TPB), 0, st, ws, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;

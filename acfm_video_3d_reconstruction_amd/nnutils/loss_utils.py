@@ -144,7 +144,7 @@ def bds_loss(verts, bds, faces, pix_to_face, reduce=True, n_samples=1000, k=1):
     indices = torch.randperm(bds.shape[1])[:n_samples]  # CPU generator, like the reference (:211)
     if bds.shape[1] > n_samples:
         bds = bds[..., indices.to(bds.device), :]
-    vis = ops.visible_vertices(pix_to_face.detach(), faces, nv)
+    vis = ops.visible_vertices(pix_to_face, faces, nv)
     loss = ops.bds_loss_per_mesh(verts, bds, vis)
     if reduce:
         return loss.mean()
@@ -229,9 +229,9 @@ def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=
     with torch.no_grad():
         faces_bt = faces.reshape(bt, faces.shape[2], 3).long()
         if pix_to_face is None:
-            pix_to_face = renderer(predicted_points.reshape(bt, nv, 3), faces_bt).long()
-        else:
-            pix_to_face = pix_to_face[..., :1].long()
+            pix_to_face = renderer(predicted_points.reshape(bt, nv, 3), faces_bt)
+        elif pix_to_face.shape[-1] != 1:
+            pix_to_face = pix_to_face[..., :1]
         visible_vertices = ops.visible_vertices(pix_to_face, faces_bt, nv).reshape(b, t, nv)
 
     pts = predicted_points[:, :, None, :2]

@@ -78,21 +78,23 @@ class _SilRender(torch.autograd.Function):
         F, H = f.shape[1], int(img_size)
         mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
         p2f = torch.empty((N, H, H, K), dtype=torch.int64, device=v.device)
+        kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
+        vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         ws, nb = _workspace(N, V, F, v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, float(blur), float(sigma),
-                float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(ws), nb,
-                _lib.cur_stream(v.device)), "acfm_sil_forward")
-        ctx.save_for_backward(v, f, c, mask, p2f)
-        ctx.cfg = (H, K, float(sigma), float(offset_z))
-        ctx.mark_non_differentiable(p2f)
-        return mask, p2f
+                float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
+                _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_sil_forward")
+        ctx.save_for_backward(v, f, c, mask, kth)
+        ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
+        ctx.mark_non_differentiable(p2f, vis)
+        return mask, p2f, vis
 
     @staticmethod
-    def backward(ctx, gmask, _gp2f):
-        v, f, c, mask, p2f = ctx.saved_tensors
-        H, K, sigma, offset_z = ctx.cfg
+    def backward(ctx, gmask, _gp2f, _gvis):
+        v, f, c, mask, kth = ctx.saved_tensors
+        H, blur, sigma, offset_z = ctx.cfg
         N, V, _ = v.shape
         F = f.shape[1]
         g = _f32c(gmask)
@@ -101,15 +103,20 @@ class _SilRender(torch.autograd.Function):
         ws, nb = _workspace(N, V, F, v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_backward(
-                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(g), N,
-                V, F, H, K, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb,
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
+                V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb,
                 _lib.cur_stream(v.device)), "acfm_sil_backward")
         return gv, None, gc, None, None, None, None, None
 
 
 def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0):
-    """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,K] i64)."""
-    return _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z)
+    """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,K] i64).
+    The visible-vertex bitmap the raster kernel produces on the side (vertices of every
+    nearest face, = what bds_loss / optical_flow_loss derive from pix_to_face[..., 0]) rides
+    along on the pix_to_face tensor object as `._acfm_vis`."""
+    mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z)
+    p2f._acfm_vis = vis
+    return mask, p2f
 
 
 # ------------------------------------------------------------------------------ hard raster
@@ -121,11 +128,13 @@ def hard_raster(verts_proj, faces, img_size):
     f = expand_faces(faces, N)
     F, H = f.shape[1], int(img_size)
     p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+    vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
     ws, nb = _workspace(N, V, F, v.device)
     with torch.cuda.device(v.device):
         _lib.check(_lib.lib().acfm_hard_raster(_lib.ptr(v), _lib.ptr(f), N, V, F, H, _lib.ptr(p2f),
-                                               _lib.ptr(ws), nb, _lib.cur_stream(v.device)),
-                   "acfm_hard_raster")
+                                               _lib.ptr(vis), _lib.ptr(ws), nb,
+                                               _lib.cur_stream(v.device)), "acfm_hard_raster")
+    p2f._acfm_vis = vis
     return p2f
 
 
@@ -218,7 +227,12 @@ def mask_losses(mask, gt=None, edt=None):
 
 # ------------------------------------------------------------------------------ boundary loss
 def visible_vertices(pix_to_face, faces, nv):
-    """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv]."""
+    """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv].  A pix_to_face tensor that
+    comes straight from sil_render / hard_raster carries the bitmap already (fused into the
+    raster kernel); any other tensor goes through the stand-alone kernel."""
+    fused = getattr(pix_to_face, "_acfm_vis", None)
+    if fused is not None and fused.shape == (pix_to_face.shape[0], nv):
+        return fused
     _lib.require_gpu(pix_to_face, faces)
     p = pix_to_face.detach().to(torch.int64).contiguous()
     N, K = p.shape[0], p.shape[-1]

@@ -91,27 +91,32 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F);
  * rasterize_meshes(K, blur_radius, bin_size=None) -> sigmoid_alpha_blend(sigma).
  *   verts_world [N,V,3] f32, faces [N,F,3] i64, cams [N,7] f32
  *   -> mask [N,H,H] f32, pix_to_face [N,H,H,K] i64 (packed ids, ascending depth, -1 empty)
- * `ws` is kept by the caller until acfm_sil_backward of the same call has run. */
+ *   -> kth [N,H,H] u64 (optional, NULL to skip): state for acfm_sil_backward -- the
+ *      (depth bits << 32 | face) key of the K-th kept face where K faces were kept, else ~0
+ *   -> vis [N,V] u8 (optional): 1 for every vertex of a face that is nearest in some pixel,
+ *      i.e. the visible-vertex set of loss_utils.bds_loss (:214-224), fused into the raster
+ * K in {2,4,8,10,20,32}. */
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N,
                      int V, int F, int H, int K, float blur_radius, float sigma, float offset_z,
-                     float* mask, int64_t* pix_to_face, void* ws, size_t ws_bytes, void* stream);
+                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
- * (dists path) + the projection chain.  grad_mask [N,H,H] -> grad_verts [N,V,3],
- * grad_cams [N,7] (either may be NULL).  Recomputes the face setup from verts/cams, so
- * `ws` does not have to survive from the forward call. */
+ * (dists path) + the projection chain.  mask / kth are the forward's outputs;
+ * grad_mask [N,H,H] -> grad_verts [N,V,3], grad_cams [N,7] (either may be NULL).
+ * Re-runs the face setup from verts/cams: `ws` need not survive from the forward call. */
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
-                      const float* mask, const int64_t* pix_to_face, const float* grad_mask,
-                      int N, int V, int F, int H, int K, float sigma, float offset_z,
-                      float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
-                      void* stream);
+                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                      int F, int H, float blur_radius, float sigma, float offset_z,
+                      float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
  * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are
  * ALREADY projected by proj_fn; no y flip; view R=diag(-1,1,1), T=(0,0,2.732).
  * -> pix_to_face [N,H,H,1] i64 */
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
-                     int64_t* pix_to_face, void* ws, size_t ws_bytes, void* stream);
+                     int64_t* pix_to_face, uint8_t* vis /* optional [N,V], as above */, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* ---- atlas-textured render -----------------------------------------------------------
  * replaces NeuralRenderer.forward, texture branch with atlas=True
