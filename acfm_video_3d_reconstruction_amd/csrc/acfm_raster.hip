@@ -12,11 +12,10 @@
 //     tile, each wave64 an 8x8 pixel block.  Faces are binned against the tile with wave
 //     ballots into an LDS candidate list (deterministic, face-ordered, one barrier per 256
 //     faces); every lane then walks the list with LDS broadcast reads.
-//   * forward, K > 1: a lane appends its (depth, face) keys to ITS OWN K slots of the
-//     pix_to_face output (used as scratch, so no per-pixel LDS lists and 5 waves/SIMD instead
-//     of 2), multiplies the blend product on the fly, and finally sorts the keys in registers
-//     with a Batcher network and emits packed ids as 16-byte stores.  Pixels that saw more than
-//     K faces (replace-the-farthest path) redo their blend product over the K kept faces.
+//   * forward, K > 1: every lane keeps its pixel's K nearest (depth|face) keys and blend
+//     factors SORTED in registers (bubble-through insertion on static register indices): no
+//     per-pixel LDS or memory lists (4 waves/SIMD instead of 2), no final sort, the blend
+//     product runs over exactly the kept faces, ids leave as 16-byte stores.
 //   * backward: the same walk; membership of a face in a pixel's top-K is `key <= kth[pixel]`
 //     (kth saved by the forward), gradients of a candidate are summed across the wave with DPP
 //     row shifts/broadcasts and ONE lane adds them to the tile's LDS vertex accumulator, which
@@ -24,7 +23,6 @@
 //   * workgroups are dealt so that all tiles of a mesh run on one XCD (its face records stay
 //     in that XCD's L2).
 #include "acfm_common.h"
-#include "acfm_sortnet.h"
 
 namespace acfm {
 
@@ -144,8 +142,60 @@ struct CandList {
   float4 box[CAP], a[CAP], b[CAP];
   float2 c[CAP];    // (z2, area)
   int fid[CAP];
+  unsigned short sub[4][CAP];  // per-wave: candidates whose box meets the wave's 8x8 block
   int wcnt[2][4];
 };
+
+struct Cand {
+  float4 box, a, b;
+  float2 c;
+  int fid, idx;
+};
+
+__device__ __forceinline__ Cand load_cand(const CandList& L, int i) {
+  Cand r;
+  r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i]; r.c = L.c[i]; r.fid = L.fid[i]; r.idx = i;
+  return r;
+}
+
+// Second-level cull + walk, per wave: (A) 64 candidates at a time, lane i tests candidate i
+// against the wave's own 8x8 pixel block and the survivors are compacted (ballot) into the
+// wave's sub-list; (B) the sub-list is walked with the next record prefetched from LDS while
+// the current one is processed.  body(cand, in_box, ordinal) runs for every lane; in_box is
+// the per-pixel box test, ordinal the wave-uniform position in the sub-list.
+template <class Body>
+__device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int list_n, Body&& body) {
+  // extent of this wave's block (pixel centres)
+  const int by = (t.yi & ~7), bx = (t.xi & ~7);
+  const float w_xmax = pix_to_ndc(H - 1 - bx, H), w_xmin = pix_to_ndc(H - 1 - (bx + 7), H);
+  const float w_ymax = pix_to_ndc(H - 1 - by, H), w_ymin = pix_to_ndc(H - 1 - (by + 7), H);
+  unsigned short* sub = L.sub[t.wv];
+  int sub_n = 0;
+  for (int base = 0; base < list_n; base += 64) {
+    const int c = base + t.lane;
+    bool hit = false;
+    if (c < list_n) {
+      const float4 b = L.box[c];
+      hit = !((w_xmin > b.y) | (w_xmax < b.x) | (w_ymin > b.w) | (w_ymax < b.z));
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (hit) sub[sub_n + __popcll(bal & ((1ull << t.lane) - 1ull))] = (unsigned short)c;
+    sub_n += __popcll(bal);
+  }
+  if (sub_n == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  Cand nxt = load_cand(L, sub[0]);
+  int i2 = sub[min(1, sub_n - 1)];
+  for (int i = 0; i < sub_n; ++i) {
+    const Cand cur = nxt;
+    nxt = load_cand(L, i2);
+    i2 = sub[min(i + 2, sub_n - 1)];
+    const bool in_box = !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
+    body(cur, in_box, i);
+  }
+}
 
 // Bins the F faces of mesh t.n against the tile and calls walk(count) (all threads, uniform)
 // whenever the LDS list is complete or could overflow.  WITH_VIDX also stages the vertex ids.
@@ -196,10 +246,31 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
   }
 }
 
-struct Hit { float pz, sd, c0, c1; };
+struct Hit { float pz, sd, c0, c1, d01, d02, d12; };
+
+// PointLineDistanceForward with t = dot * rcp(l2) (1-ulp reciprocal).  The unclamped t sits at
+// the minimum of |a + t(b-a) - p|^2, so a 1-ulp error in t changes d only to second order;
+// clamped t (0 or 1) is exact either way.
+__device__ __forceinline__ float point_line_dist_fast(float px, float py, float ax, float ay, float bx,
+                                                      float by) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  const float dxb = px - bx, dyb = py - by;
+  float t = (bax * (px - ax) + bay * (py - ay)) * __builtin_amdgcn_rcpf(l2);
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float qx = ax + t * bax, qy = ay + t * bay;
+  const float dx = qx - px, dy = qy - py;
+  return (l2 <= ACFM_K_EPS) ? (dxb * dxb + dyb * dyb) : (dx * dx + dy * dy);
+}
 
 // One pixel against one face, in the oracle's operation order (oracle_rasterize).
-template <bool CLIP>
+// FAST (kept for experiments, NOT used by the shipped kernels: the rounding of the foot point
+// q = a + t(b-a) makes d sensitive to the last bit of t at the 1e-6 level, so only the exact
+// division keeps the mask within 1e-6 of the oracle): edge distances with the fast reciprocal; any pixel whose accept/reject decision could
+// depend on the last bits of d (|d - blur| within 1e-5 relative, not inside) is redone with the
+// exact IEEE divisions, so the kept SET of faces -- and with it pix_to_face -- is bit-identical
+// to the oracle; only the blend probability sees the (second-order) difference.
+template <bool CLIP, bool FAST>
 __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, const float4& B,
                                           float z2, float area, float blur, Hit& h) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
@@ -218,14 +289,34 @@ __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, c
   }
   const float pz = c0 * z0 + c1 * z1 + c2 * z2;
   if (pz < 0.0f) return false;
-  const float d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-  const float d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
-  const float d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
-  const float d = fminf(fminf(d01, d02), d12);
   const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  float d01, d02, d12;
+  if (FAST) {
+    d01 = point_line_dist_fast(xf, yf, x0, y0, x1, y1);
+    d02 = point_line_dist_fast(xf, yf, x0, y0, x2, y2);
+    d12 = point_line_dist_fast(xf, yf, x1, y1, x2, y2);
+    const float dq = fminf(fminf(d01, d02), d12);
+    if (!inside && fabsf(dq - blur) <= 1e-5f * blur) {
+      d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
+      d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
+      d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
+    }
+  } else {
+    d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
+    d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
+    d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
+  }
+  const float d = fminf(fminf(d01, d02), d12);
   if (!inside && d >= blur) return false;
   h.pz = pz; h.sd = inside ? -d : d; h.c0 = c0; h.c1 = c1;
+  h.d01 = d01; h.d02 = d02; h.d12 = d12;
   return true;
+}
+
+// blend probability sigmoid(-sd/sigma): exact sd/sigma and library expf like the oracle, only
+// the final reciprocal is the 1-ulp v_rcp_f32 (error <= 6e-8 per face, mask tolerance 1e-6)
+__device__ __forceinline__ float sigmoid_neg_fast(float sd, float sigma) {
+  return __builtin_amdgcn_rcpf(1.0f + expf(sd / sigma));
 }
 
 // (depth, face) key: pz >= 0 so its bit pattern orders like the float; +0.0f folds -0.0 into
@@ -250,17 +341,6 @@ struct FwdOut {
   float gamma;
 };
 
-template <int K> struct SortNet;
-#define ACFM_CE(i, j) { const unsigned long long a_ = k[i], b_ = k[j]; const bool s_ = a_ > b_; \
-                        k[i] = s_ ? b_ : a_; k[j] = s_ ? a_ : b_; }
-#define ACFM_DEF_SORT(KK)                                                             \
-  template <> struct SortNet<KK> {                                                    \
-    static __device__ __forceinline__ void run(unsigned long long (&k)[KK]) {         \
-      ACFM_SORTNET_##KK(ACFM_CE)                                                      \
-    }                                                                                 \
-  };
-ACFM_DEF_SORT(2) ACFM_DEF_SORT(4) ACFM_DEF_SORT(8) ACFM_DEF_SORT(10) ACFM_DEF_SORT(20) ACFM_DEF_SORT(32)
-
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
   const int4 vi = ws.vidx[(size_t)n * F + f];
   uint8_t* v = out.vis + (size_t)n * out.V;
@@ -279,16 +359,13 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
     unsigned long long bestkey = KEY_NONE;
     float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f;
     bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
-      if (!t.valid) return;
-      for (int c = 0; c < list_n; ++c) {
-        const float4 bx = L.box[c];
-        if (t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z) continue;
-        const float2 C = L.c[c];
+      walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
+        if (!(in_box && t.valid)) return;
         Hit h;
-        if (!test_face<CLIP>(t.xf, t.yf, L.a[c], L.b[c], C.x, C.y, blur, h)) continue;
-        const unsigned long long key = make_key(h.pz, L.fid[c]);
+        if (!test_face<CLIP, false>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
+        const unsigned long long key = make_key(h.pz, cd.fid);
         if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; }
-      }
+      });
     });
     if (!t.valid) return;
     const bool hit = (bestkey != KEY_NONE);
@@ -328,78 +405,39 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
       }
     }
   } else {
-    // this pixel's K output slots double as the key list while the tile is walked
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(out.p2f) + t.pix * K;
-    int cnt = 0;
-    bool overflow = false;               // a face was dropped/replaced: alpha must be redone
-    unsigned long long maxkey = 0; int maxslot = 0;   // valid when cnt == K
-    float alpha = 1.0f;
+    // Per-pixel top-K list: K (depth|face) keys + their blend factors (1 - p), kept SORTED in
+    // registers.  A new face is bubbled through the array with compare-exchanges on static
+    // register indices (the displaced farthest entry falls off the end), so there is no LDS or
+    // memory list, no final sort and the kept set is exactly the K nearest at every moment.
+    unsigned long long key[K];
+    float q[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
-      if (!t.valid) return;
-      for (int c = 0; c < list_n; ++c) {
-        const float4 bx = L.box[c];
-        if (t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z) continue;
-        const float2 C = L.c[c];
+      walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
+        if (!(in_box && t.valid)) return;
         Hit h;
-        if (!test_face<CLIP>(t.xf, t.yf, L.a[c], L.b[c], C.x, C.y, blur, h)) continue;
-        const unsigned long long key = make_key(h.pz, L.fid[c]);
-        bool rescan = false;
-        if (cnt < K) {
-          slots[cnt] = key;
-          alpha = alpha * (1.0f - sigmoid_neg(h.sd, sigma));
-          cnt++;
-          rescan = (cnt == K);
-        } else {
-          overflow = true;
-          if (key < maxkey) { slots[maxslot] = key; rescan = true; }
+        if (!test_face<CLIP, false>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
+        unsigned long long x = make_key(h.pz, cd.fid);
+        float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const bool sw = x < key[k];
+          const unsigned long long tk = key[k];
+          const float tq = q[k];
+          key[k] = sw ? x : tk; x = sw ? tk : x;
+          q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
         }
-        if (rescan) {  // rare: find the farthest kept face again
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          maxkey = 0; maxslot = 0;
-          for (int k = 0; k < K; ++k) {
-            const unsigned long long kk = slots[k];
-            if (kk >= maxkey) { maxkey = kk; maxslot = k; }
-          }
-        }
-      }
+      });
     });
     if (!t.valid) return;
-    longlong2* o2 = reinterpret_cast<longlong2*>(out.p2f + t.pix * K);  // K even -> 16-B aligned
-    if (cnt == 0) {
+    float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
 #pragma unroll
-      for (int k2 = 0; k2 < K / 2; ++k2) o2[k2] = make_longlong2(-1, -1);
-      out.mask[t.pix] = 0.0f;
-      if (out.kth) out.kth[t.pix] = KEY_NONE;
-      return;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own appends have landed before the read-back
-    unsigned long long key[K];
-#pragma unroll
-    for (int k2 = 0; k2 < K / 2; ++k2) {
-      const longlong2 v = o2[k2];
-      key[2 * k2] = (2 * k2 < cnt) ? (unsigned long long)v.x : KEY_NONE;
-      key[2 * k2 + 1] = (2 * k2 + 1 < cnt) ? (unsigned long long)v.y : KEY_NONE;
-    }
-    SortNet<K>::run(key);
-    if (overflow) {
-      // blend over exactly the K kept faces (ascending depth), distances recomputed
-      alpha = 1.0f;
-      for (int k = 0; k < K; ++k) {
-        // static register index: walk a copy of the sorted keys through slot 0
-        unsigned long long kk = key[0];
-#pragma unroll
-        for (int j = 1; j < K; ++j) kk = (j == k) ? key[j] : kk;
-        const size_t o = (size_t)n * F + (size_t)(kk & 0xffffffffu);
-        const float4 C = ws.recC[o];
-        Hit h;
-        h.sd = 0.f;
-        test_face<CLIP>(t.xf, t.yf, ws.recA[o], ws.recB[o], C.x, C.y, blur, h);
-        alpha = alpha * (1.0f - sigmoid_neg(h.sd, sigma));
-      }
-    }
+    for (int k = 0; k < K; ++k) alpha = alpha * q[k];
     out.mask[t.pix] = 1.0f - alpha;
-    if (out.kth) out.kth[t.pix] = (cnt == K) ? key[K - 1] : KEY_NONE;
-    if (out.vis) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
+    if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
+    if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
+    longlong2* o2 = reinterpret_cast<longlong2*>(out.p2f + t.pix * K);  // K even -> 16-B aligned
 #pragma unroll
     for (int k2 = 0; k2 < K / 2; ++k2) {
       longlong2 v;
@@ -473,17 +511,15 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
 
   bin_and_walk<true>(ws, t, F, L, s_vidx, [&](int list_n) {
     if (__ballot(work) == 0ull) return;  // nothing to do in this 8x8 block
-    for (int c = 0; c < list_n; ++c) {
-      const float4 bx = L.box[c];
-      bool member = work && !(t.xf > bx.y || t.xf < bx.x || t.yf > bx.w || t.yf < bx.z);
-      if (__ballot(member) == 0ull) continue;
-      const float4 A = L.a[c], B = L.b[c];
-      const float2 C = L.c[c];
+    walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
+      bool member = work && in_box;
+      if (__ballot(member) == 0ull) return;
+      const float4 A = cd.a, B = cd.b;
       Hit h;
-      h.pz = 0.f; h.sd = 0.f;
-      member = member && test_face<false>(t.xf, t.yf, A, B, C.x, C.y, blur, h);
-      member = member && (make_key(h.pz, L.fid[c]) <= kthkey);
-      if (__ballot(member) == 0ull) continue;
+      h.pz = 0.f; h.sd = 0.f; h.d01 = 0.f; h.d02 = 0.f; h.d12 = 0.f;
+      member = member && test_face<false, false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, blur, h);
+      member = member && (make_key(h.pz, cd.fid) <= kthkey);
+      if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
       if (member) {
         const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
@@ -491,14 +527,11 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
         const bool inside = h.sd < 0.0f;
         const float gs = coef * sigmoid_neg(h.sd, sigma);   // dL / d sd
         const float gd = inside ? -gs : gs;                 // sd = inside ? -d : d
-        const float d01 = point_line_dist(t.xf, t.yf, x0, y0, x1, y1);
-        const float d02 = point_line_dist(t.xf, t.yf, x0, y0, x2, y2);
-        const float d12 = point_line_dist(t.xf, t.yf, x1, y1, x2, y2);
         float ax_, ay_, bx_, by_;
-        if (d01 <= d02 && d01 <= d12) {
+        if (h.d01 <= h.d02 && h.d01 <= h.d12) {
           point_line_dist_bwd(t.xf, t.yf, x0, y0, x1, y1, gd, ax_, ay_, bx_, by_);
           g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_;
-        } else if (d02 <= d01 && d02 <= d12) {
+        } else if (h.d02 <= h.d01 && h.d02 <= h.d12) {
           point_line_dist_bwd(t.xf, t.yf, x0, y0, x2, y2, gd, ax_, ay_, bx_, by_);
           g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_;
         } else {
@@ -510,12 +543,12 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
       g1x = wave_sum_dpp(g1x); g1y = wave_sum_dpp(g1y);
       g2x = wave_sum_dpp(g2x); g2y = wave_sum_dpp(g2y);
       if (t.lane == 0) {
-        const int4 vi = s_vidx[c];
+        const int4 vi = s_vidx[cd.idx];
         atomicAdd(&s_g[2 * vi.x], g0x); atomicAdd(&s_g[2 * vi.x + 1], g0y);
         atomicAdd(&s_g[2 * vi.y], g1x); atomicAdd(&s_g[2 * vi.y + 1], g1y);
         atomicAdd(&s_g[2 * vi.z], g2x); atomicAdd(&s_g[2 * vi.z + 1], g2y);
       }
-    }
+    });
   });
   __syncthreads();
   float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
