@@ -89,6 +89,7 @@ class _SilRender(torch.autograd.Function):
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
         ctx.mark_non_differentiable(p2f, vis)
+        ctx.set_materialize_grads(False)  # no zero-filled [N,H,H,K] int64 "gradient" for pix_to_face
         return mask, p2f, vis
 
     @staticmethod
@@ -97,6 +98,8 @@ class _SilRender(torch.autograd.Function):
         H, blur, sigma, offset_z = ctx.cfg
         N, V, _ = v.shape
         F = f.shape[1]
+        if gmask is None:
+            return None, None, None, None, None, None, None, None
         g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
@@ -163,6 +166,7 @@ class _TexRender(torch.autograd.Function):
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R)
         ctx.mark_non_differentiable(sil, p2f)
+        ctx.set_materialize_grads(False)
         return imgs, sil, p2f
 
     @staticmethod
@@ -170,7 +174,7 @@ class _TexRender(torch.autograd.Function):
         (tidx,) = ctx.saved_tensors
         N, F, H, R = ctx.cfg
         ga = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and gimgs is not None:
             g = _f32c(gimgs)
             ga = torch.empty((N, F, R, R, 3), dtype=torch.float32, device=g.device)
             with torch.cuda.device(g.device):

@@ -1,0 +1,79 @@
+"""Frame sharding over the GPUs of one node.
+
+The reference only has single-process nn.DataParallel (multiframe/main.py:172-193).  Here:
+one process per GPU, clips (pairs of frames + all their camera hypotheses) are dealt in
+contiguous blocks, per-frame parameters stay on the owning rank, and the ONLY exchange per
+step is one all-reduce (RCCL over xGMI; `nccl` backend) of a flat fp32 buffer holding the
+gradients of the shared parameters (mean shape, handle weights, loss scalars).  The buffer is
+<= ~200 KB, i.e. latency-bound: one collective, no bucketing."""
+import torch
+import torch.distributed as dist
+
+
+def clip_shard(num_clips, rank, world):
+    """Contiguous block of clips for `rank`: sizes differ by at most one."""
+    base, rem = divmod(num_clips, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def frame_shard(num_clips, frames_per_clip, rank, world):
+    """Frame index range owned by `rank`; both frames of a clip (and hence the optical-flow
+    pair, loss_utils.py:457, and the hypothesis softmax, main.py:736) stay on one rank."""
+    s, e = clip_shard(num_clips, rank, world)
+    return s * frames_per_clip, e * frames_per_clip
+
+
+class SharedGradReducer:
+    """Sums the gradients of the shared parameters over ranks with ONE collective.
+
+    deterministic=True uses all_gather + a fixed-order local sum, so every rank gets a
+    bit-identical result independent of the collective's internal reduction order."""
+
+    def __init__(self, params, group=None, average=False, deterministic=False):
+        self.params = list(params)
+        self.group = group
+        self.average = average
+        self.deterministic = deterministic
+        self.numel = sum(p.numel() for p in self.params)
+        self._flat = None
+
+    def _buffer(self, ref):
+        if self._flat is None or self._flat.device != ref.device:
+            self._flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
+        return self._flat
+
+    def reduce(self, extra_scalars=None):
+        """All-reduce p.grad of every shared parameter in place.  `extra_scalars`: optional 1-D
+        fp32 tensor appended to the same buffer (loss values for logging) and returned summed."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        ref = next(p for p in self.params)
+        n_extra = 0 if extra_scalars is None else extra_scalars.numel()
+        flat = self._buffer(ref)
+        if n_extra and flat.numel() != self.numel + n_extra:
+            self._flat = flat = torch.zeros(self.numel + n_extra, dtype=torch.float32, device=ref.device)
+        o = 0
+        for p in self.params:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            flat[o:o + p.numel()].copy_(g.reshape(-1))
+            o += p.numel()
+        if n_extra:
+            flat[o:o + n_extra].copy_(extra_scalars.reshape(-1))
+        if world > 1:
+            if self.deterministic:
+                parts = [torch.empty_like(flat) for _ in range(world)]
+                dist.all_gather(parts, flat, group=self.group)
+                flat.zero_()
+                for part in parts:
+                    flat.add_(part)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            flat[:self.numel].div_(world)
+        o = 0
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        return flat[o:o + n_extra].clone() if n_extra else None

@@ -35,8 +35,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define K_EPS 1e-8f
 #define MAXK 64
+
+/* number of host threads for the parallel loops (used by bench.py's cpu_baseline leg) */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------ projection */
 /* geom_utils.hamilton_product (geom_utils.py:107-131): same operand order, same

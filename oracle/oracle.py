@@ -47,6 +47,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """OpenMP threads for the C loops; returns the count in effect."""
+    return int(lib().oracle_set_threads(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 

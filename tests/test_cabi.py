@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/acfm_hip.h declares; the Python layer refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "acfm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(acfm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from acfm_video_3d_reconstruction_amd import _lib
+    _lib.build()
+    assert os.path.exists(_lib.SO_PATH)
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for name in syms:
+        assert hasattr(raw, name), "libacfm_hip.so does not export %s" % name
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    h = _lib.lib()
+    assert h.acfm_arch() == b"gfx950"
+    assert h.acfm_raster_workspace_bytes(64, 642, 1280) > 0
+    assert h.acfm_raster_workspace_bytes(0, 642, 1280) == 0
+
+
+def test_no_cpu_fallback():
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    v = torch.zeros(1, 4, 3)
+    f = torch.zeros(1, 2, 3, dtype=torch.int64)
+    c = torch.zeros(1, 7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        NeuralRenderer(32)(v, f, c)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.project(v, c)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the product package may reference it."""
+    pkg = os.path.join(ROOT, "acfm_video_3d_reconstruction_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+                assert "libacfm_oracle" not in src, fn
+                assert '#include "../../oracle' not in src and "oracle/acfm_oracle" not in src.replace(
+                    "oracle/acfm_oracle.c is the bit-level spec", ""), fn
