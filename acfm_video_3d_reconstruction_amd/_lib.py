@@ -22,11 +22,11 @@ SIGNATURES = {
     "acfm_prof_name": (ctypes.c_char_p, [_i]),
     "acfm_project": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i]),
+    "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
                               _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
-                               _sz, _vp]),
+                               _sz, _i, _vp]),
     "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "acfm_tex_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
                               _vp, _sz, _vp]),

@@ -42,12 +42,14 @@ struct RasterWs {
   int4* vidx;      // [N,F] (i0,i1,i2,-)
   float4* mbox;    // [N]   union of the face boxes
   float* grad_ndc; // [N,V,2]
+  int* tile_cnt;   // [N,tiles^2] faces whose box meets the tile (cost estimate for scheduling)
+  int* order;      // [N*tiles^2] heavy-first visiting order of (mesh, tile) per XCD group
   size_t bytes;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline RasterWs carve_ws(void* base, int N, int V, int F) {
+static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   RasterWs w;
   char* p = (char*)base;
   size_t o = 0;
@@ -59,6 +61,9 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F) {
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
   w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
+  const size_t tt = (size_t)((H + 15) / 16) * ((H + 15) / 16);
+  w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
+  w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
   w.bytes = o;
   return w;
 }

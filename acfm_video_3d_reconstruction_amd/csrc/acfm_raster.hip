@@ -30,18 +30,24 @@ constexpr int TILE = 16;      // pixels per tile side (PyTorch3D's auto bin size
 constexpr int TPB = 256;      // threads per workgroup = TILE*TILE
 constexpr int CAP = 512;      // LDS candidate-list capacity (walked early when it could overflow)
 constexpr unsigned long long KEY_NONE = ~0ull;
+constexpr int SETUP_LDS_TILES = 4096;  // tile counters kept in LDS up to 1024x1024 images
 
 // ------------------------------------------------------------------------------- setup
 // mode 0: verts are world coordinates -> project with cams, flip y   (nmr.py:145-149)
 // mode 1: verts are already projected, no y flip                     (nmr.py:224-238)
 __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
-                                               const float* __restrict__ cams, int V, int F,
+                                               const float* __restrict__ cams, int V, int F, int H,
                                                float offset_z, int mode, float margin, RasterWs ws) {
-  extern __shared__ float s_v[];  // [V][3]
+  extern __shared__ float s_v[];  // [V][3] then, if it fits, [tiles^2] int tile counters
   __shared__ float s_red[4][4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* cam = cams ? cams + 7 * (size_t)n : nullptr;
+  const int tiles_ = (H + TILE - 1) / TILE, tt_ = tiles_ * tiles_;
+  const bool lds_cnt = tt_ <= SETUP_LDS_TILES;
+  int* s_cnt = reinterpret_cast<int*>(s_v + 3 * V);
+  if (lds_cnt)
+    for (int i = tid; i < tt_; i += TPB) s_cnt[i] = 0;
   for (int v = tid; v < V; v += TPB) {
     const float* x = verts + ((size_t)n * V + v) * 3;
     float px, py, pz;
@@ -83,17 +89,91 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     ws.recC[o] = make_float4(z2, area, 0.f, 0.f);
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
+    if (!degenerate) {
+      // cost estimate for heavy-first scheduling: +1 on every tile the box may touch
+      // (pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack)
+      const int tiles = (H + TILE - 1) / TILE;
+      const float hf = (float)H;
+      int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+      int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+      int ya = (int)floorf(hf - 1.0f - ((b.w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+      int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+      if (xb >= 0 && yb >= 0 && xa < H && ya < H) {
+        xa = max(xa, 0) / TILE; ya = max(ya, 0) / TILE;
+        xb = min(xb, H - 1) / TILE; yb = min(yb, H - 1) / TILE;
+        if ((xb - xa + 1) * (yb - ya + 1) <= 64)
+          for (int ty = ya; ty <= yb; ++ty)
+            for (int tx = xa; tx <= xb; ++tx) {
+              if (lds_cnt) atomicAdd(&s_cnt[ty * tiles + tx], 1);
+              else atomicAdd(&ws.tile_cnt[((size_t)n * tiles + ty) * tiles + tx], 1);
+            }
+      }
+    }
   }
   bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
   const int w = tid >> 6;
   if ((tid & 63) == 0) { s_red[w][0] = bx0; s_red[w][1] = bx1; s_red[w][2] = by0; s_red[w][3] = by1; }
   __syncthreads();
+  if (lds_cnt)
+    for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i];
   if (tid == 0) {
     for (int i = 1; i < 4; ++i) {
       bx0 = fminf(bx0, s_red[i][0]); bx1 = fmaxf(bx1, s_red[i][1]);
       by0 = fminf(by0, s_red[i][2]); by1 = fmaxf(by1, s_red[i][3]);
     }
     ws.mbox[n] = make_float4(bx0, bx1, by0, by1);
+  }
+}
+
+// ------------------------------------------------------------------------------- scheduling
+// Heavy-first order.  Per-tile work is heavy-tailed (dense clusters of tiny faces: a tile can
+// take 20x the average), so every XCD group visits its (mesh, tile) entries in descending cost
+// class; the long tiles start first and the short ones fill in behind them.
+// Entry e of group g  <->  mesh (e / tt) * G + g, tile e % tt   (G = 8 groups if N % 8 == 0, else 1).
+constexpr int NCLASS = 7;
+__device__ __forceinline__ int cost_class(int c) {
+  return c >= 192 ? 0 : c >= 128 ? 1 : c >= 96 ? 2 : c >= 64 ? 3 : c >= 32 ? 4 : c >= 1 ? 5 : 6;
+}
+__global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
+  __shared__ int s_hist[NCLASS], s_base[NCLASS];
+  const int G = gridDim.x, g = blockIdx.x, lane = threadIdx.x & 63;
+  const int per = (N / G) * tt;
+  if (threadIdx.x < NCLASS) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int iters = (per + (int)blockDim.x - 1) / (int)blockDim.x;
+  // pass 1: class histogram (one LDS atomic per wave and class)
+  for (int it = 0; it < iters; ++it) {
+    const int e = it * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (e < per) cls = cost_class(ws.tile_cnt[(size_t)((e / tt) * G + g) * tt + (e % tt)]);
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m != 0ull && lane == (int)__ffsll((long long)m) - 1) atomicAdd(&s_hist[c], __popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 0; c < NCLASS; ++c) { s_base[c] = acc; acc += s_hist[c]; }
+  }
+  __syncthreads();
+  // pass 2: scatter (order inside a class is arbitrary: results never depend on it)
+  int* ord = ws.order + (size_t)g * per;
+  for (int it = 0; it < iters; ++it) {
+    const int e = it * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (e < per) cls = cost_class(ws.tile_cnt[(size_t)((e / tt) * G + g) * tt + (e % tt)]);
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m == 0ull) continue;
+      const int leader = (int)__ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&s_base[c], __popcll(m));
+      base = __shfl(base, leader, 64);
+      if (cls == c) ord[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
   }
 }
 
@@ -106,22 +186,25 @@ struct Tile {
   float t_xmin, t_xmax, t_ymin, t_ymax;
 };
 
-// Workgroup -> (mesh, tile).  Workgroups are dealt round-robin over the 8 XCDs, so with
-// N % 8 == 0 mesh n is pinned to the blocks b with b % 8 == n % 8 (one XCD's L2 then holds the
-// records of the meshes it renders).  Pure speed: any mapping gives the same result.
-__device__ __forceinline__ Tile make_tile(int N, int H) {
+// Workgroup -> (mesh, tile) through the heavy-first order of its XCD group.  Workgroups are
+// dealt round-robin over the 8 XCDs, so with N % 8 == 0 group g = b % 8 owns the meshes
+// n % 8 == g (one XCD's L2 then holds the records of the meshes it renders).  Pure speed: any
+// mapping gives the same result.
+__device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
   Tile t;
   const int tiles = (H + TILE - 1) / TILE;
   const int tt = tiles * tiles;
   const unsigned b = blockIdx.x;
   int n, tl;
   if ((N & 7) == 0) {
-    const unsigned xcd = b & 7u, j = b >> 3;
-    n = (int)(j / tt) * 8 + (int)xcd;
-    tl = (int)(j % tt);
+    const unsigned g = b & 7u, j = b >> 3;
+    const int e = ws.order[(size_t)g * ((N >> 3) * tt) + j];
+    n = (e / tt) * 8 + (int)g;
+    tl = e % tt;
   } else {
-    n = (int)(b / tt);
-    tl = (int)(b % tt);
+    const int e = ws.order[b];
+    n = e / tt;
+    tl = e % tt;
   }
   t.n = n;
   t.tid = threadIdx.x; t.wv = t.tid >> 6; t.lane = t.tid & 63;
@@ -248,31 +331,14 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
 
 struct Hit { float pz, sd, c0, c1, d01, d02, d12; };
 
-// PointLineDistanceForward with t = dot * rcp(l2) (1-ulp reciprocal).  The unclamped t sits at
-// the minimum of |a + t(b-a) - p|^2, so a 1-ulp error in t changes d only to second order;
-// clamped t (0 or 1) is exact either way.
-__device__ __forceinline__ float point_line_dist_fast(float px, float py, float ax, float ay, float bx,
-                                                      float by) {
-  const float bax = bx - ax, bay = by - ay;
-  const float l2 = bax * bax + bay * bay;
-  const float dxb = px - bx, dyb = py - by;
-  float t = (bax * (px - ax) + bay * (py - ay)) * __builtin_amdgcn_rcpf(l2);
-  t = fminf(fmaxf(t, 0.0f), 1.0f);
-  const float qx = ax + t * bax, qy = ay + t * bay;
-  const float dx = qx - px, dy = qy - py;
-  return (l2 <= ACFM_K_EPS) ? (dxb * dxb + dyb * dyb) : (dx * dx + dy * dy);
-}
-
-// One pixel against one face, in the oracle's operation order (oracle_rasterize).
-// FAST (kept for experiments, NOT used by the shipped kernels: the rounding of the foot point
-// q = a + t(b-a) makes d sensitive to the last bit of t at the 1e-6 level, so only the exact
-// division keeps the mask within 1e-6 of the oracle): edge distances with the fast reciprocal; any pixel whose accept/reject decision could
-// depend on the last bits of d (|d - blur| within 1e-5 relative, not inside) is redone with the
-// exact IEEE divisions, so the kept SET of faces -- and with it pix_to_face -- is bit-identical
-// to the oracle; only the blend probability sees the (second-order) difference.
-template <bool CLIP, bool FAST>
-__device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, const float4& B,
-                                          float z2, float area, float blur, Hit& h) {
+// One pixel against one face, split in two stages so callers can drop a face after the cheap
+// half.  Every rejection of the oracle (oracle_rasterize) is a pure filter, so evaluating
+// them in a different order keeps the accepted set -- and every accepted value -- identical.
+//   stage 1: barycentrics (IEEE divisions), depth pz, inside flag;  rejects pz < 0
+//   stage 2: the three edge distances;  rejects !inside && d >= blur
+template <bool CLIP>
+__device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4& A, const float4& B,
+                                                float z2, float area, Hit& h, bool& inside) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
   const float z0 = B.z, z1 = B.w;
   const float denom = area + ACFM_K_EPS;
@@ -288,29 +354,28 @@ __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, c
     c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
   }
   const float pz = c0 * z0 + c1 * z1 + c2 * z2;
-  if (pz < 0.0f) return false;
-  const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-  float d01, d02, d12;
-  if (FAST) {
-    d01 = point_line_dist_fast(xf, yf, x0, y0, x1, y1);
-    d02 = point_line_dist_fast(xf, yf, x0, y0, x2, y2);
-    d12 = point_line_dist_fast(xf, yf, x1, y1, x2, y2);
-    const float dq = fminf(fminf(d01, d02), d12);
-    if (!inside && fabsf(dq - blur) <= 1e-5f * blur) {
-      d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-      d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
-      d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
-    }
-  } else {
-    d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-    d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
-    d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
-  }
-  const float d = fminf(fminf(d01, d02), d12);
-  if (!inside && d >= blur) return false;
-  h.pz = pz; h.sd = inside ? -d : d; h.c0 = c0; h.c1 = c1;
-  h.d01 = d01; h.d02 = d02; h.d12 = d12;
-  return true;
+  inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  h.pz = pz; h.c0 = c0; h.c1 = c1;
+  return !(pz < 0.0f);
+}
+
+__device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4& A, const float4& B,
+                                               float blur, bool inside, Hit& h) {
+  const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
+  h.d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
+  h.d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
+  h.d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
+  const float d = fminf(fminf(h.d01, h.d02), h.d12);
+  h.sd = inside ? -d : d;
+  return inside || !(d >= blur);
+}
+
+template <bool CLIP>
+__device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, const float4& B,
+                                          float z2, float area, float blur, Hit& h) {
+  bool inside;
+  if (!test_face_depth<CLIP>(xf, yf, A, B, z2, area, h, inside)) return false;
+  return test_face_dist(xf, yf, A, B, blur, inside, h);
 }
 
 // blend probability sigmoid(-sd/sigma): exact sd/sigma and library expf like the oracle, only
@@ -327,6 +392,7 @@ __device__ __forceinline__ unsigned long long make_key(float pz, int fid) {
 
 // ------------------------------------------------------------------------------- forward
 struct FwdOut {
+  unsigned long long* dbg;   // diagnostic build only: per-block (t_start, t_end, hw_id) stamps
   float* mask;               // soft: [N,H,H]
   int64_t* p2f;              // [N,H,H,K]
   unsigned long long* kth;   // soft, optional: [N,H,H] largest kept key if K faces kept, else ~0
@@ -351,9 +417,21 @@ template <int K, bool CLIP, bool TEX>
 __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
   __shared__ CandList L;
-  const Tile t = make_tile(N, H);
+  const Tile t = make_tile(ws, N, H);
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
+  struct Stamp {
+    unsigned long long* p; unsigned long long t0;
+    __device__ Stamp(unsigned long long* q) : p(q), t0(q ? __builtin_amdgcn_s_memrealtime() : 0) {}
+    __device__ ~Stamp() {
+      if (p && threadIdx.x == 0) {
+        unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+        p[3 * (size_t)blockIdx.x] = t0; p[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+      }
+    }
+  } stamp(out.dbg);
 
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
@@ -362,7 +440,7 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
       walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
         Hit h;
-        if (!test_face<CLIP, false>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
+        if (!test_face<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
         const unsigned long long key = make_key(h.pz, cd.fid);
         if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; }
       });
@@ -415,10 +493,19 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
       walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
-        if (!(in_box && t.valid)) return;
+        // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list
+        // cannot enter it; when that holds for every lane of the wave the face is dropped
+        // before its edge distances are computed (empty slots hold ~0, so x < key[K-1] is
+        // always true for a list that is not full yet)
         Hit h;
-        if (!test_face<CLIP, false>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
+        bool inside = false;
+        bool live = in_box && t.valid &&
+                    test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside);
         unsigned long long x = make_key(h.pz, cd.fid);
+        live = live && (x < key[K - 1]);
+        if (__ballot(live) == 0ull) return;
+        if (!live) return;
+        if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
         float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -490,7 +577,7 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
   __shared__ CandList L;
   __shared__ int4 s_vidx[CAP];
   extern __shared__ float s_g[];  // [V][2] tile-local vertex gradient
-  const Tile t = make_tile(N, H);
+  const Tile t = make_tile(ws, N, H);
 
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
@@ -517,8 +604,13 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
       const float4 A = cd.a, B = cd.b;
       Hit h;
       h.pz = 0.f; h.sd = 0.f; h.d01 = 0.f; h.d02 = 0.f; h.d12 = 0.f;
-      member = member && test_face<false, false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, blur, h);
+      bool inside = false;
+      // stage 1 (depth): only faces at or before the pixel's K-th kept face took part in the
+      // blend; the others are dropped before their edge distances are computed
+      member = member && test_face_depth<false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, h, inside);
       member = member && (make_key(h.pz, cd.fid) <= kthkey);
+      if (__ballot(member) == 0ull) return;
+      if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h);
       if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
       if (member) {
@@ -671,14 +763,20 @@ void prof_end(hipStream_t st) {
 
 // ------------------------------------------------------------------------------- host side
 static int launch_setup(const float* verts, const int64_t* faces, const float* cams, int N, int V,
-                        int F, float offset_z, int mode, float blur, const RasterWs& ws,
+                        int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
                         hipStream_t st) {
   const float margin = sqrtf(blur);
-  const size_t lds = sizeof(float) * 3 * (size_t)V;
+  const int tiles = (H + TILE - 1) / TILE;
+  const int tt = tiles * tiles;
+  const size_t lds = sizeof(float) * 3 * (size_t)V + (tt <= SETUP_LDS_TILES ? sizeof(int) * (size_t)tt : 0);
   if (lds > 150 * 1024) return ACFM_E_BADARG;
+  if (tt > SETUP_LDS_TILES &&
+      hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * (size_t)N * tt, st) != hipSuccess)
+    return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
-  hipLaunchKernelGGL(k_setup, dim3(N), dim3(TPB), lds, st, verts, faces, cams, V, F, offset_z, mode,
+  hipLaunchKernelGGL(k_setup, dim3(N), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws);
+  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, tt);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -709,6 +807,8 @@ using namespace acfm;
 
 extern "C" {
 
+static unsigned long long* g_dbg = nullptr;
+int acfm_debug_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)p; return 0; }
 int acfm_version(void) { return 1001; }
 const char* acfm_arch(void) { return "gfx950"; }
 
@@ -746,9 +846,9 @@ const char* acfm_prof_name(int id) {
   return (id >= 0 && id < ACFM_PROF_NKERNELS) ? names[id] : "";
 }
 
-size_t acfm_raster_workspace_bytes(int N, int V, int F) {
-  if (N <= 0 || V <= 0 || F <= 0) return 0;
-  return carve_ws(nullptr, N, V, F).bytes;
+size_t acfm_raster_workspace_bytes(int N, int V, int F, int H) {
+  if (N <= 0 || V <= 0 || F <= 0 || H <= 0) return 0;
+  return carve_ws(nullptr, N, V, F, H).bytes;
 }
 
 int acfm_project(const float* verts, const float* cams, int N, int V, float offset_z, float* proj,
@@ -778,13 +878,14 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f)
     return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F);
+  const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, blur_radius, ws, st);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
   if (rc) return rc;
   if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
   FwdOut out = {};
+  out.dbg = g_dbg;
   out.mask = mask;
   out.p2f = pix_to_face;
   out.kth = reinterpret_cast<unsigned long long*>(kth);
@@ -804,14 +905,17 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
                       const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
-                      float* grad_cams, void* wsp, size_t ws_bytes, void* stream) {
+                      float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
+                      void* stream) {
   if (!verts_world || !faces || !cams || !mask || !kth || !grad_mask || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F);
+  const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, blur_radius, ws, st);
-  if (rc) return rc;
+  if (!ws_from_forward) {
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
+    if (rc) return rc;
+  }
   if (hipMemsetAsync(ws.grad_ndc, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
     return ACFM_E_LAUNCH;
   const size_t lds = sizeof(float) * 2 * (size_t)V;
@@ -835,13 +939,14 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
                      int64_t* pix_to_face, uint8_t* vis, void* wsp, size_t ws_bytes, void* stream) {
   if (!verts_proj || !faces || !pix_to_face || !wsp || bad_dims(N, V, F, H)) return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F);
+  const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, 0.f, 1, 0.f, ws, st);
+  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, st);
   if (rc) return rc;
   if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
   FwdOut out = {};
+  out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.vis = vis;
   out.V = V;
@@ -860,12 +965,13 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
   if ((size_t)N * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;  // texel_idx is int32
-  const RasterWs ws = carve_ws(wsp, N, V, F);
+  const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, offset_z, 0, 0.f, ws, st);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
   if (rc) return rc;
   FwdOut out = {};
+  out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);

@@ -28,8 +28,8 @@ def expand_faces(faces, N):
     return faces.to(torch.int64).contiguous()
 
 
-def _workspace(N, V, F, device):
-    nbytes = _lib.lib().acfm_raster_workspace_bytes(N, V, F)
+def _workspace(N, V, F, H, device):
+    nbytes = _lib.lib().acfm_raster_workspace_bytes(N, V, F, H)
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
@@ -80,7 +80,7 @@ class _SilRender(torch.autograd.Function):
         p2f = torch.empty((N, H, H, K), dtype=torch.int64, device=v.device)
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
-        ws, nb = _workspace(N, V, F, v.device)
+        ws, nb = _workspace(N, V, F, H, v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, float(blur), float(sigma),
@@ -88,6 +88,7 @@ class _SilRender(torch.autograd.Function):
                 _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_sil_forward")
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
+        ctx.ws = (ws, nb)  # face records + tile schedule: reused by backward (no second setup)
         ctx.mark_non_differentiable(p2f, vis)
         ctx.set_materialize_grads(False)  # no zero-filled [N,H,H,K] int64 "gradient" for pix_to_face
         return mask, p2f, vis
@@ -103,11 +104,11 @@ class _SilRender(torch.autograd.Function):
         g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
-        ws, nb = _workspace(N, V, F, v.device)
+        ws, nb = ctx.ws
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_backward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
-                V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb,
+                V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
                 _lib.cur_stream(v.device)), "acfm_sil_backward")
         return gv, None, gc, None, None, None, None, None
 
@@ -132,7 +133,7 @@ def hard_raster(verts_proj, faces, img_size):
     F, H = f.shape[1], int(img_size)
     p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
     vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
-    ws, nb = _workspace(N, V, F, v.device)
+    ws, nb = _workspace(N, V, F, H, v.device)
     with torch.cuda.device(v.device):
         _lib.check(_lib.lib().acfm_hard_raster(_lib.ptr(v), _lib.ptr(f), N, V, F, H, _lib.ptr(p2f),
                                                _lib.ptr(vis), _lib.ptr(ws), nb,
@@ -157,7 +158,7 @@ class _TexRender(torch.autograd.Function):
         sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
         p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
         tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
-        ws, nb = _workspace(N, V, F, v.device)
+        ws, nb = _workspace(N, V, F, H, v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),

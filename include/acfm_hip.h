@@ -81,9 +81,9 @@ int acfm_project_backward(const float* verts, const float* cams, const float* gr
                           int V, float* grad_verts, float* grad_cams, void* stream);
 
 /* ---- rasterisation workspace -------------------------------------------------------
- * One workspace serves forward and backward of a render call of N meshes with V verts and
- * F faces each (face records, NDC verts, per-mesh boxes, gradient scratch). */
-size_t acfm_raster_workspace_bytes(int N, int V, int F);
+ * Scratch of one render call of N meshes with V verts and F faces each at H x H pixels
+ * (face records, NDC verts, per-mesh boxes, tile schedule, gradient scratch). */
+size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
 
 /* ---- soft silhouette ---------------------------------------------------------------
  * replaces NeuralRenderer.forward, mask branch (multiframe/nnutils/nmr.py:143-172):
@@ -104,11 +104,13 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
  * grad_mask [N,H,H] -> grad_verts [N,V,3], grad_cams [N,7] (either may be NULL).
- * Re-runs the face setup from verts/cams: `ws` need not survive from the forward call. */
+ * ws_from_forward != 0: `ws` is the untouched workspace of the matching acfm_sil_forward call
+ * (same verts/faces/cams/H/blur) and the face setup is not repeated; 0: it is rebuilt here. */
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
                       const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z,
-                      float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes, void* stream);
+                      float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
+                      int ws_from_forward, void* stream);
 
 /* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
  * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are

@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
     h = _lib.lib()
     assert h.acfm_arch() == b"gfx950"
-    assert h.acfm_raster_workspace_bytes(64, 642, 1280) > 0
-    assert h.acfm_raster_workspace_bytes(0, 642, 1280) == 0
+    assert h.acfm_raster_workspace_bytes(64, 642, 1280, 256) > 0
+    assert h.acfm_raster_workspace_bytes(0, 642, 1280, 256) == 0
 
 
 def test_no_cpu_fallback():

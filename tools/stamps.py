@@ -1,0 +1,47 @@
+"""Diagnostic: per-workgroup start/end stamps of the raster kernels (s_memrealtime, 100 MHz)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from acfm_video_3d_reconstruction_amd import _lib, ops
+from acfm_video_3d_reconstruction_amd.synthetic import batch_verts, make_cams
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = sys.argv[2] if len(sys.argv) > 2 else "sil"
+H = 256
+dev = torch.device("cuda:0")
+m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
+v, f = m["bird_v"], m["bird_f"]
+rng = np.random.default_rng(1000)
+verts = torch.tensor(batch_verts(v, N, rng, 0.005), device=dev)
+cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=dev)
+faces = torch.tensor(f, device=dev)[None].repeat(N, 1, 1).contiguous()
+atlas = torch.rand(N, f.shape[0], 6, 6, 3, device=dev)
+raw = ctypes.CDLL(_lib.SO_PATH)
+nb = N * 256
+buf = torch.zeros(nb * 3, dtype=torch.int64, device=dev)
+def run():
+    if mode == "sil": ops.sil_render(verts, faces, cams, H)
+    else: ops.tex_render(verts, faces, cams, atlas, H)
+for _ in range(3): run()
+torch.cuda.synchronize()
+raw.acfm_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+run(); torch.cuda.synchronize()
+raw.acfm_debug_set_stamp_buffer(None)
+b = buf.cpu().numpy().reshape(nb, 3)
+t0, t1, hw = b[:, 0], b[:, 1], b[:, 2]
+dur = (t1 - t0) / 100.0  # us
+span = (t1.max() - t0.min()) / 100.0
+xcc = hw >> 32
+cu = (hw & 0xffffffff)
+print("blocks", nb, "kernel span %.1f us" % span, "block dur: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (
+    dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+print("sum of block durations %.0f us -> /1280 slots = %.1f us" % (dur.sum(), dur.sum() / 1280))
+start = (t0 - t0.min()) / 100.0
+print("start time percentiles (us): p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(start, [10, 50, 90, 100])))
+for x in range(8):
+    sel = xcc == x
+    if sel.any():
+        print("xcc", x, "blocks", sel.sum(), "meshes", sorted(set(((np.nonzero(sel)[0] >> 3) // 256 * 8 + (np.nonzero(sel)[0] & 7)).tolist()))[:10],
+              "last end %.1f" % ((t1[sel].max() - t0.min()) / 100.0), "sum dur %.0f" % dur[sel].sum())
+order = np.argsort(-dur)[:8]
+print("heaviest blocks:", [(int(i), round(float(dur[i]), 1), round(float(start[i]), 1)) for i in order])
