@@ -122,9 +122,9 @@ def main():
     mean_p = mean_v.clone().requires_grad_(True)
     reducer = SharedGradReducer([mean_p])  # one flat fp32 all-reduce (RCCL) per step
 
+    params = [delta, cams, mean_p, atlas]
+
     def step():
-        for t in (delta, cams, mean_p, atlas):
-            t.grad = None
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
         mask, p2f = renderer(pred_v, faces, cams)                        # a3
         l1, iou, e = L.fused_silhouette_losses(mask, gt_mask, edt)       # a10, a11
@@ -134,10 +134,13 @@ def main():
         if a.tex:
             tex, _, _ = renderer(pred_v.detach(), faces, cams, textures=atlas)   # a4
             total = total + 0.5 * ((tex - imgs_gt) * gt_mask[:, None]).pow(2).mean()
-        total.backward()
+        # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
+        # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
+        g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+        mean_p.grad = g_mean
         if world > 1:  # the one exchange: shared mean-shape gradient + loss scalar
             reducer.reduce(extra_scalars=total.detach().reshape(1))
-        return total
+        return total, g_delta, g_cams, g_atlas
 
     def fence():
         torch.cuda.synchronize()

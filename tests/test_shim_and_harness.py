@@ -1,0 +1,140 @@
+"""CPU: host-side logic around the kernels -- PyTorch3D API shim, trainer harness helpers,
+deformation solver -- against the oracle and the reference's golden outputs."""
+import io
+
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import oracle as O
+
+from acfm_video_3d_reconstruction_amd import harness
+from acfm_video_3d_reconstruction_amd import pytorch3d_shim as p3d
+from acfm_video_3d_reconstruction_amd.deform import DeformSolver, deform_reference_formula
+from acfm_video_3d_reconstruction_amd.nnutils import geom_utils, loss_utils
+from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
+
+T = torch.from_numpy
+
+
+def test_meshes_packed_views(meshes):
+    v, f = T(meshes["bird_v"]), T(meshes["bird_f"])
+    ms = Meshes(verts=v[None].repeat(3, 1, 1), faces=f[None].repeat(3, 1, 1))
+    assert len(ms) == 3 and not ms.isempty()
+    assert ms.verts_packed().shape == (3 * 642, 3)
+    fp = ms.faces_packed()
+    assert fp.shape == (3 * 1280, 3) and fp[1280:2560].min() >= 642 and fp[2560:].max() == 3 * 642 - 1
+    e1 = O.edges_packed(meshes["bird_f"])
+    e = ms.edges_packed().numpy()
+    assert e.shape == (3 * 1920, 2)
+    np.testing.assert_array_equal(e[:1920], e1)
+    np.testing.assert_array_equal(e[1920:3840], e1 + 642)
+    ms2 = Meshes(verts=[v, v[:100]], faces=[f, f[:10] % 100])     # list form, unequal sizes
+    assert ms2.verts_packed().shape[0] == 742 and ms2.verts_padded().shape == (2, 642, 3)
+    assert list(ms2.num_verts_per_mesh()) == [642, 100]
+
+
+def test_laplacian_smoothing_and_subdivide(meshes):
+    v, f = T(meshes["horse_v"]), T(meshes["horse_f"])
+    vb = (v[None].repeat(2, 1, 1) + 0.01 * torch.randn(2, 642, 3, generator=torch.Generator().manual_seed(0)))
+    vb.requires_grad_(True)
+    ms = Meshes(verts=vb, faces=f[None].repeat(2, 1, 1))
+    a = p3d.loss.mesh_laplacian_smoothing(ms, "cot")
+    vr = vb.detach().clone().requires_grad_(True)
+    b = O.laplacian_smoothing_cot(vr, f)
+    np.testing.assert_allclose(a.item(), b.item(), rtol=1e-5)
+    a.backward()
+    b.backward()
+    np.testing.assert_allclose(vb.grad.numpy(), vr.grad.numpy(), rtol=1e-3, atol=1e-6)
+    u = p3d.loss.mesh_laplacian_smoothing(ms, "uniform")
+    assert u.item() > 0
+    one = Meshes(verts=[v], faces=[f])
+    out = p3d.ops.SubdivideMeshes(one)(one)
+    ov, of = O.subdivide(meshes["horse_v"], meshes["horse_f"])
+    np.testing.assert_allclose(out.verts_packed().numpy(), ov, atol=1e-7)
+    np.testing.assert_array_equal(out.faces_packed().numpy(), of)
+
+
+def test_load_obj_both_face_syntaxes():
+    txt = "mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1/ 2/2/ 3/3/ \nf 1 3 4\nf 1 2 3 4\n"
+    v, faces, aux = p3d.io.load_obj(io.StringIO(txt))
+    assert v.shape == (4, 3) and faces.verts_idx.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 3]]
+    assert aux.verts_uvs.shape == (3, 2)
+
+
+def test_transforms_and_camera_harness():
+    g = torch.Generator().manual_seed(1)
+    q = torch.nn.functional.normalize(torch.randn(6, 4, generator=g), dim=-1)
+    R = p3d.transforms.quaternion_to_matrix(q)
+    np.testing.assert_allclose(p3d.transforms.matrix_to_quaternion(R).numpy(),
+                               p3d.transforms.standardize_quaternion(q).numpy(), atol=1e-5)
+    a, b = q[:3, None], q[3:, None]
+    np.testing.assert_allclose(p3d.transforms.quaternion_raw_multiply(a, b).numpy(),
+                               geom_utils.hamilton_product(a, b).numpy(), atol=1e-7)
+    # mirroring: projected x and z flip sign, y stays (main.py:113-125)
+    cams = torch.cat([torch.rand(6, 1, generator=g) + 0.5, torch.rand(6, 2, generator=g) - 0.5, q], 1)
+    X = torch.randn(6, 20, 3, generator=g)
+    flag = torch.tensor([1, 0, 1, 1, 0, 1.])[:, None]
+    cm = harness.mirror_cameras(cams, None, flag)
+    p0, p1 = O.project_torch(X, cams), O.project_torch(X, cm)
+    m = flag[:, :, None].bool().expand_as(p0)
+    np.testing.assert_allclose(p1[..., 0][m[..., 0]].numpy(), -p0[..., 0][m[..., 0]].numpy(), atol=1e-5)
+    np.testing.assert_allclose(p1[..., 1].numpy(), p0[..., 1].numpy(), atol=1e-5)
+    np.testing.assert_allclose(p1[..., 2][m[..., 2]].numpy(), -p0[..., 2][m[..., 2]].numpy(), atol=1e-5)
+    np.testing.assert_allclose(p1[~m].numpy(), p0[~m].numpy(), atol=0)
+    # affine transform of the camera == affine transform of the projected points
+    tr = torch.tensor([[1.3, 0.1, -0.2, 1.0]]).repeat(6, 1)
+    ct = harness.transform_cameras(cams, None, tr)
+    p2 = O.project_torch(X, ct)
+    np.testing.assert_allclose(p2[..., :2].numpy(), (1.3 * p0[..., :2] + torch.tensor([0.1, -0.2])).numpy(), atol=1e-5)
+    emb = torch.randn(4, 7, generator=g)
+    dc = harness.decode_cameras(emb, 0.5)
+    np.testing.assert_allclose(dc[:, 3:].norm(dim=-1).numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(dc[:, 0].numpy(), np.maximum(0.5 * emb[:, 0].numpy() + 1, 0) + 1e-12, atol=1e-7)
+    L = torch.rand(5, 8, generator=g).requires_grad_(True)
+    tot, probs, mean = harness.hypothesis_weighting(L)
+    np.testing.assert_allclose(probs.sum(0).numpy(), 1.0, atol=1e-6)
+    tot.backward()
+    np.testing.assert_allclose(L.grad.numpy(), probs.numpy() / 8, atol=1e-7)   # weights are detached
+
+
+def test_product_laplacian_rigid_and_solve_vs_reference_golden(meshes):
+    g, gl, gs = load_golden("losses"), load_golden("laplacian"), load_golden("solve")
+    for name in ("bird", "horse"):
+        v, f = T(meshes[name + "_v"]), T(meshes[name + "_f"])
+        L = geom_utils.mesh_laplacian(Meshes(verts=[v], faces=[f]), "cot").numpy()
+        ref = np.zeros_like(L)
+        ij = gl[name + "_ij"]
+        ref[ij[:, 0], ij[:, 1]] = gl[name + "_val"]
+        np.testing.assert_allclose(L, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    v, f = T(meshes["bird_v"]), T(meshes["bird_f"])
+    faces4 = f[None].repeat(4, 1, 1)
+    r = loss_utils.locally_rigid_fn(Meshes(verts=T(g["rigid_v"]), faces=faces4),
+                                    Meshes(verts=v[None].repeat(4, 1, 1), faces=faces4))
+    np.testing.assert_allclose(r.item(), g["rigid"], rtol=1e-5)
+    for tag, tol_ref in (("bird_k16", 2e-4), ("horse_k16", 5e-3)):
+        name = tag.split("_")[0]
+        v, f = T(meshes[name + "_v"]), T(meshes[name + "_f"])
+        logits, delta = T(gs[tag + "_logits"]), T(gs[tag + "_delta"])
+        solver = DeformSolver(v, f, logits)
+        out = solver(delta)
+        assert np.abs(out.numpy() - gs[tag + "_pred_v"]).max() < tol_ref       # the reference's fp32 Cholesky
+        L64 = O.laplacian_cot(v.double(), f)
+        truth = O.deform_solve(logits, v, delta, L64).numpy()                  # fp64 formula = parity target
+        assert np.abs(out.numpy() - truth).max() < 1e-4
+        lit = deform_reference_formula(logits.double(), v.double(), delta.double(), L64)
+        assert np.abs(lit.numpy() - truth).max() < 1e-9
+        # gradients: d delta = P^T g, d mean = sum_n g, d lbs through the fp64 factorisation
+        lg = torch.nn.Parameter(logits.clone())
+        s2 = DeformSolver(v, f, lg)
+        d2 = delta.clone().requires_grad_(True)
+        mp = v.clone().requires_grad_(True)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+        (s2(d2, mean_override=mp) * w).sum().backward()
+        lr = logits.double().clone().requires_grad_(True)
+        dr = delta.double().clone().requires_grad_(True)
+        (O.deform_solve(lr, v, dr, L64) * w.double()).sum().backward()
+        np.testing.assert_allclose(d2.grad.numpy(), dr.grad.numpy(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(mp.grad.numpy(), w.sum(0).numpy(), rtol=1e-5, atol=1e-6)
+        sc = np.abs(lr.grad.numpy()).max()
+        np.testing.assert_allclose(lg.grad.numpy(), lr.grad.numpy(), rtol=1e-2, atol=1e-3 * sc)
