@@ -33,6 +33,8 @@ SIGNATURES = {
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_visible_vertices": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_bds_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_bds_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

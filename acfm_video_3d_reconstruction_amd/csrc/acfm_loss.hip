@@ -70,6 +70,52 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses_bwd(const float* __restric
   }
 }
 
+// masked texture MSE (multiframe/main.py:655-662): per mesh mean over (3,H,W) of
+// (tex*m - img*m)^2; out[n] accumulated with one atomic per block.
+__global__ __launch_bounds__(LTPB) void k_tex_mse(const float* __restrict__ tex,
+                                                  const float* __restrict__ img,
+                                                  const float* __restrict__ m, int HW,
+                                                  float* __restrict__ out) {
+  __shared__ float s_red[4];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const size_t b3 = (size_t)n * 3 * HW, b1 = (size_t)n * HW;
+  const int start = blockIdx.x * PIX_PER_BLOCK;
+  const int end = min(start + PIX_PER_BLOCK, HW);
+  float acc = 0.f;
+  for (int i = start + tid; i < end; i += LTPB) {
+    const float mk = m[b1 + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = tex[b3 + (size_t)c * HW + i] * mk - img[b3 + (size_t)c * HW + i] * mk;
+      acc += d * d;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&out[n], (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (3.0f * (float)HW));
+}
+
+__global__ __launch_bounds__(LTPB) void k_tex_mse_bwd(const float* __restrict__ tex,
+                                                      const float* __restrict__ img,
+                                                      const float* __restrict__ m,
+                                                      const float* __restrict__ go, int HW,
+                                                      float* __restrict__ gtex) {
+  const int n = blockIdx.y;
+  const size_t b3 = (size_t)n * 3 * HW, b1 = (size_t)n * HW;
+  const float w = go[n] * 2.0f / (3.0f * (float)HW);
+  const int start = blockIdx.x * PIX_PER_BLOCK;
+  const int end = min(start + PIX_PER_BLOCK, HW);
+  for (int i = start + threadIdx.x; i < end; i += LTPB) {
+    const float mk = m[b1 + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t o = b3 + (size_t)c * HW + i;
+      gtex[o] = w * (tex[o] * mk - img[o] * mk) * mk;
+    }
+  }
+}
+
 __global__ void k_visible(const int64_t* __restrict__ p2f, const int64_t* __restrict__ faces, int V,
                           int F, int HW, int K, uint8_t* __restrict__ vis) {
   const int n = blockIdx.y;
@@ -162,6 +208,30 @@ int acfm_mask_losses_backward(const float* mask, const float* gt, const float* e
   ProfScope ps(ACFM_PROF_MASK_LOSS_BWD, (hipStream_t)stream);
   hipLaunchKernelGGL(k_mask_losses_bwd, dim3(chunks, N), dim3(LTPB), 0, (hipStream_t)stream, mask, gt,
                      edt, grad_out, HW, grad_mask);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, float* out,
+                 void* stream) {
+  if (!tex || !img || !mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  ProfScope ps(ACFM_PROF_TEX_MSE, st);
+  hipLaunchKernelGGL(k_tex_mse, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st, tex,
+                     img, mask, HW, out);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_tex_mse_backward(const float* tex, const float* img, const float* mask, const float* grad_out,
+                          int N, int HW, float* grad_tex, void* stream) {
+  if (!tex || !img || !mask || !grad_out || !grad_tex || N <= 0 || N > 65535 || HW <= 0)
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(ACFM_PROF_TEX_MSE_BWD, st);
+  hipLaunchKernelGGL(k_tex_mse_bwd, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st,
+                     tex, img, mask, grad_out, HW, grad_tex);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

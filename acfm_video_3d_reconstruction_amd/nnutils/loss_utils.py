@@ -135,6 +135,13 @@ def texture_loss(img_pred, img_gt, mask_pred, mask_gt):
     return F.l1_loss(img_pred * mask_pred.unsqueeze(1), img_gt * mask_gt.unsqueeze(1))
 
 
+def masked_texture_mse(texture_pred, imgs, masks):
+    """The texture MSE term the reference writes inline (multiframe/main.py:655-662):
+    F.mse_loss(texture_pred * masks[:, None], imgs * masks[:, None], reduction='none').mean((1, 2, 3))
+    -> [N], fused into one pass (imgs / masks are constants)."""
+    return ops.tex_mse(texture_pred, imgs, masks)
+
+
 def bds_loss(verts, bds, faces, pix_to_face, reduce=True, n_samples=1000, k=1):
     """loss_utils.py:204-237.  verts [B,V,2] projected vertices, bds [B,P,3] = (x, y, valid),
     pix_to_face [B,H,W,K] (slot 0 = nearest face)."""

@@ -230,6 +230,41 @@ def mask_losses(mask, gt=None, edt=None):
     return _MaskLosses.apply(mask, gt, edt)
 
 
+class _TexMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, img, mask):
+        _lib.require_gpu(tex, img, mask)
+        t, i, m = _f32c(tex), _f32c(img), _f32c(mask)
+        N = t.shape[0]
+        HW = m[0].numel()
+        if t.shape != i.shape or t.shape[1] != 3 or t[0, 0].numel() != HW:
+            raise ValueError("tex/img must be [N,3,H,W] and mask [N,H,W]")
+        out = torch.empty((N,), dtype=torch.float32, device=t.device)
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib().acfm_tex_mse(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), N, HW, _lib.ptr(out),
+                                               _lib.cur_stream(t.device)), "acfm_tex_mse")
+        ctx.save_for_backward(t, i, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        t, i, m = ctx.saved_tensors
+        N = t.shape[0]
+        HW = m[0].numel()
+        g = _f32c(go)
+        gt = torch.empty_like(t)
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib().acfm_tex_mse_backward(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), _lib.ptr(g),
+                                                        N, HW, _lib.ptr(gt), _lib.cur_stream(t.device)),
+                       "acfm_tex_mse_backward")
+        return gt, None, None
+
+
+def tex_mse(tex, img, mask):
+    """mean over (3,H,W) of (tex*mask - img*mask)^2 per mesh -> [N]; gradient to tex only."""
+    return _TexMSE.apply(tex, img, mask)
+
+
 # ------------------------------------------------------------------------------ boundary loss
 def visible_vertices(pix_to_face, faces, nv):
     """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv].  A pix_to_face tensor that

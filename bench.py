@@ -133,7 +133,7 @@ def main():
         total = (l1 + 0.1 * e + 0.1 * bdt).mean()
         if a.tex:
             tex, _, _ = renderer(pred_v.detach(), faces, cams, textures=atlas)   # a4
-            total = total + 0.5 * ((tex - imgs_gt) * gt_mask[:, None]).pow(2).mean()
+            total = total + 0.5 * L.masked_texture_mse(tex, imgs_gt, gt_mask).mean()     # main.py:655-662
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
         g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)

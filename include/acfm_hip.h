@@ -63,6 +63,8 @@ const char* acfm_arch(void);         /* "gfx950" */
 #define ACFM_PROF_BDS 10
 #define ACFM_PROF_BDS_BWD 11
 #define ACFM_PROF_PROJECT 12
+#define ACFM_PROF_TEX_MSE 13
+#define ACFM_PROF_TEX_MSE_BWD 14
 #define ACFM_PROF_NKERNELS 16
 #define ACFM_PROF_RING 8192
 int acfm_prof_enable(int on);
@@ -147,6 +149,15 @@ int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N
 int acfm_mask_losses_backward(const float* mask, const float* gt, const float* edt,
                               const float* grad_out, int N, int HW, float* grad_mask,
                               void* stream);
+
+/* ---- masked texture MSE ---------------------------------------------------------------
+ * replaces the inline texture term of multiframe/main.py:655-662,
+ * F.mse_loss(texture_pred * mask, imgs * mask, reduction='none').mean((1,2,3)):
+ *   tex, img [N,3,HW] f32, mask [N,HW] f32 -> out [N]; backward -> grad_tex [N,3,HW]. */
+int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, float* out,
+                 void* stream);
+int acfm_tex_mse_backward(const float* tex, const float* img, const float* mask,
+                          const float* grad_out, int N, int HW, float* grad_tex, void* stream);
 
 /* ---- visibility + boundary loss ------------------------------------------------------
  * visible-vertex bitmap shared by loss_utils.bds_loss (:214-224) and optical_flow_loss
