@@ -1,0 +1,178 @@
+"""GPU: edge cases and full-size properties of the raster path (BASELINE.json configs 1-5)."""
+import numpy as np
+import pytest
+import torch
+
+from acfm_video_3d_reconstruction_amd.synthetic import batch_verts, make_cams
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _check_sil(verts, f, cams, H, K=20, check_bwd=True, seed=0):
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    n = verts.shape[0]
+    ref_mask, ref_p2f = O.sil_render(verts, f, cams, H, K=K)
+    tv = torch.tensor(verts, device=d, requires_grad=True)
+    tc = torch.tensor(cams, device=d, requires_grad=True)
+    mask, p2f = ops.sil_render(tv, torch.from_numpy(f).to(d), tc, H, K=K)
+    np.testing.assert_array_equal(p2f.cpu().numpy(), ref_p2f)
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), ref_mask, rtol=0, atol=1e-6)
+    if check_bwd:
+        g = (np.random.default_rng(seed).standard_normal((n, H, H)) / (H * H)).astype(np.float32)
+        gv, gc, _, _ = O.sil_render_backward(verts, f, cams, H, g, K=K)
+        (mask * torch.tensor(g, device=d)).sum().backward()
+        sv, sc = max(np.abs(gv).max(), 1e-20), max(np.abs(gc).max(), 1e-20)
+        np.testing.assert_allclose(tv.grad.cpu().numpy(), gv, rtol=1e-4, atol=1e-4 * sv)
+        np.testing.assert_allclose(tc.grad.cpu().numpy(), gc, rtol=1e-4, atol=1e-4 * sc)
+    return ref_p2f
+
+
+def test_odd_image_size_and_batch_not_multiple_of_8(meshes):
+    rng = np.random.default_rng(1)
+    v, f = meshes["cow_v"], meshes["cow_f"]
+    verts = batch_verts(v, 3, rng)
+    cams = make_cams(3, rng, extent=float(np.abs(v).max()))
+    p = _check_sil(verts, f, cams, 100)
+    assert (p[..., 0] >= 0).mean() > 0.02
+
+
+def test_subdivided_template_many_binning_rounds(meshes):
+    """BASELINE config 5 shape: 2562 verts / 5120 faces (one SubdivideMeshes pass)."""
+    rng = np.random.default_rng(2)
+    v, f = O.subdivide(meshes["horse_v"], meshes["horse_f"])
+    verts = batch_verts(v.astype(np.float32), 2, rng, 0.003)
+    cams = make_cams(2, rng, extent=float(np.abs(v).max()))
+    p = _check_sil(verts, f.astype(np.int64), cams, 128)
+    assert (p[..., 19] >= 0).sum() > 0                      # K-truncation exercised
+
+
+def test_whole_mesh_in_one_tile_list_overflow(meshes):
+    """Tiny scale: all 1280 faces land in a couple of tiles -> the LDS candidate list is walked in
+    several rounds and almost every pixel overflows K."""
+    rng = np.random.default_rng(3)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    verts = batch_verts(v, 2, rng)
+    cams = make_cams(2, rng, extent=float(np.abs(v).max()))
+    cams[:, 0] *= 0.03
+    _check_sil(verts, f, cams, 64)
+
+
+def test_mesh_outside_image_and_degenerate_faces(meshes):
+    rng = np.random.default_rng(4)
+    v, f = meshes["bird_v"], meshes["bird_f"].copy()
+    verts = batch_verts(v, 2, rng)
+    cams = make_cams(2, rng, extent=float(np.abs(v).max()))
+    cams[0, 1] = 5.0                                           # frame 0 entirely off-screen
+    f[:40, 2] = f[:40, 1]                                      # 40 zero-area faces
+    p = _check_sil(verts, f, cams, 64)
+    assert (p[0] == -1).all() and (p[1, ..., 0] >= 0).any()
+
+
+@pytest.mark.parametrize("K", [2, 32])
+def test_other_K(meshes, K):
+    rng = np.random.default_rng(5)
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    verts = batch_verts(v, 2, rng)
+    cams = make_cams(2, rng, extent=float(np.abs(v).max()))
+    _check_sil(verts, f, cams, 64, K=K)
+
+
+def test_monocular_offset_z_and_non_unit_quaternion(meshes):
+    """monocular/nnutils/nmr.py:164 uses offset_z = 5; proj_fn does not normalise the quaternion."""
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _dev()
+    rng = np.random.default_rng(6)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    verts = batch_verts(v, 2, rng)
+    cams = make_cams(2, rng, extent=float(np.abs(v).max()))
+    cams[:, 3:] *= 1.1
+    r = NeuralRenderer(64)
+    r.offset_z = 5.
+    mask, p2f = r(torch.from_numpy(verts).to(d), torch.from_numpy(f)[None].repeat(2, 1, 1).to(d),
+                  torch.from_numpy(cams).to(d))
+    ref_mask, ref_p2f = O.sil_render(verts, f, cams, 64, offset_z=5.0)
+    np.testing.assert_array_equal(p2f.cpu().numpy(), ref_p2f)
+    np.testing.assert_allclose(mask.cpu().numpy(), ref_mask, atol=1e-6)
+
+
+def test_full_size_properties_config2(meshes):
+    """BASELINE config 2 (bird, 64 frames @256^2): size-independent properties on the whole batch +
+    oracle comparison on two of its frames."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    rng = np.random.default_rng(1000)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    N, H, K, F = 64, 256, 20, f.shape[0]
+    verts = batch_verts(v, N, rng, 0.005)
+    cams = make_cams(N, rng, extent=float(np.abs(v).max()))
+    tv = torch.tensor(verts, device=d, requires_grad=True)
+    tc = torch.tensor(cams, device=d, requires_grad=True)
+    tf = torch.from_numpy(f).to(d)
+    mask, p2f = ops.sil_render(tv, tf, tc, H)
+    assert bool(((mask >= 0) & (mask <= 1)).all())
+    valid = p2f >= 0
+    assert bool(((mask > 0) == valid[..., 0]).all())                       # mask > 0 <=> a face is kept
+    assert bool((valid[..., 1:] <= valid[..., :-1]).all())                 # -1 only as a trailing run
+    base = (torch.arange(N, device=d) * F)[:, None, None, None]
+    assert bool(((p2f >= base) & (p2f < base + F) | ~valid).all())         # packed ids stay in their mesh
+    srt = torch.sort(torch.where(valid, p2f, torch.arange(K, device=d) - 1000), dim=-1)[0]
+    assert bool((srt[..., 1:] != srt[..., :-1]).all())                     # no face twice in a pixel
+    np.testing.assert_array_equal(p2f._acfm_vis.cpu().numpy(),
+                                  ops.visible_vertices(p2f.clone(), tf, v.shape[0]).cpu().numpy())
+    # backward is linear in the upstream gradient
+    g1 = torch.randn(N, H, H, device=d) / (H * H)
+    g2 = torch.randn(N, H, H, device=d) / (H * H)
+
+    def grads(g):
+        gv, gc = torch.autograd.grad((mask * g).sum(), [tv, tc], retain_graph=True)
+        return gv, gc
+    a, b, c = grads(g1), grads(g2), grads(2.0 * g1 - 0.5 * g2)
+    for i in range(2):
+        want = 2.0 * a[i] - 0.5 * b[i]
+        assert float((c[i] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9
+    # two frames against the oracle at full size
+    sel = [3, 41]
+    ref_mask, ref_p2f = O.sil_render(verts[sel], f, cams[sel], H)
+    got = p2f[sel].cpu().numpy() - (np.array(sel) * F)[:, None, None, None] + (np.arange(2) * F)[:, None, None, None]
+    got = np.where(p2f[sel].cpu().numpy() >= 0, got, -1)
+    np.testing.assert_array_equal(got, ref_p2f)
+    np.testing.assert_allclose(mask[sel].detach().cpu().numpy(), ref_mask, atol=1e-6)
+
+
+def test_texture_and_flow_on_quadruped_clip(meshes):
+    """BASELINE config 3 shape (horse clip): texture render + optical-flow loss on paired frames."""
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer, OF_NeuralRenderer
+    d = _dev()
+    rng = np.random.default_rng(8)
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    b, t, H = 3, 2, 96
+    verts = batch_verts(v, b * t, rng, 0.01)
+    cams = make_cams(b * t, rng, extent=float(np.abs(v).max()))
+    flows = (rng.standard_normal((b, t, H, H, 2)) * (rng.uniform(size=(b, t, H, H, 1)) > 0.3)).astype(np.float32)
+    faces = torch.from_numpy(f)[None, None].repeat(b, t, 1, 1)
+    tm = torch.tensor(verts.reshape(b, t, -1, 3), device=d, requires_grad=True)
+    loss, of_pred, vis, _, _ = L.optical_flow_loss(tm, faces.to(d), torch.from_numpy(cams).to(d),
+                                                   torch.from_numpy(flows).to(d), OF_NeuralRenderer(H), None,
+                                                   reduce=False)
+    rm = torch.tensor(verts.reshape(b, t, -1, 3), dtype=torch.float64, requires_grad=True)
+    rl, rp, rv = O.optical_flow_loss(rm, faces, torch.from_numpy(cams).double(), torch.from_numpy(flows).double(),
+                                     None, reduce=False)
+    np.testing.assert_array_equal(vis.cpu().numpy(), rv.numpy())
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), rl.detach().numpy(), rtol=1e-4, atol=1e-6)
+    loss.sum().backward()
+    rl.sum().backward()
+    np.testing.assert_allclose(tm.grad.cpu().numpy(), rm.grad.numpy(), rtol=1e-3, atol=1e-4 * np.abs(rm.grad.numpy()).max())
+    atlas = rng.uniform(0, 1, (b * t, f.shape[0], 4, 4, 3)).astype(np.float32)
+    imgs, sil, p2f = NeuralRenderer(H)(torch.from_numpy(verts).to(d), faces.reshape(b * t, -1, 3).to(d),
+                                       torch.from_numpy(cams).to(d), textures=torch.from_numpy(atlas).to(d))
+    ri, rs, rp2, _ = O.tex_render(verts, f, cams, atlas, H)
+    np.testing.assert_array_equal(p2f.cpu().numpy(), rp2)
+    np.testing.assert_allclose(imgs.cpu().numpy(), ri, atol=1e-6)
