@@ -23,8 +23,8 @@ SIGNATURES = {
     "acfm_project": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
-                              _vp]),
+    "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                              _sz, _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
                                _sz, _i, _vp]),
     "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

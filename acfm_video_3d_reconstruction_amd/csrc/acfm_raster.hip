@@ -394,7 +394,8 @@ __device__ __forceinline__ unsigned long long make_key(float pz, int fid) {
 struct FwdOut {
   unsigned long long* dbg;   // diagnostic build only: per-block (t_start, t_end, hw_id) stamps
   float* mask;               // soft: [N,H,H]
-  int64_t* p2f;              // [N,H,H,K]
+  int64_t* p2f;              // [N,H,H,kout]
+  int kout;                  // soft: K (all kept faces) or 1 (nearest face only)
   unsigned long long* kth;   // soft, optional: [N,H,H] largest kept key if K faces kept, else ~0
   uint8_t* vis;              // optional: [N,V] vertices of every nearest face
   int V;
@@ -524,6 +525,12 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
     out.mask[t.pix] = 1.0f - alpha;
     if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
     if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
+    if (out.kout == 1) {
+      // lean output: only the nearest-face plane, the one slot any caller of the reference
+      // reads (loss_utils.py:214, 431); the other K-1 ids stay in registers
+      out.p2f[t.pix] = (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1;
+      return;
+    }
     longlong2* o2 = reinterpret_cast<longlong2*>(out.p2f + t.pix * K);  // K even -> 16-B aligned
 #pragma unroll
     for (int k2 = 0; k2 < K / 2; ++k2) {
@@ -872,11 +879,12 @@ int acfm_project_backward(const float* verts, const float* cams, const float* gr
 }
 
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
-                     int F, int H, int K, float blur_radius, float sigma, float offset_z, float* mask,
-                     int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp, size_t ws_bytes,
-                     void* stream) {
+                     int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
+                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                     size_t ws_bytes, void* stream) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
-  if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f)
+  if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
+      (k_out != K && k_out != 1))
     return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
@@ -888,6 +896,7 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   out.dbg = g_dbg;
   out.mask = mask;
   out.p2f = pix_to_face;
+  out.kout = k_out;
   out.kth = reinterpret_cast<unsigned long long*>(kth);
   out.vis = vis;
   out.V = V;

@@ -20,9 +20,14 @@ class NeuralRenderer(torch.nn.Module):
     it in nn.DataParallel, main.py:183-193); honours the input tensors' device and the
     current HIP stream."""
 
-    def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4):
+    def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4, pix_to_face_slots=None):
+        """pix_to_face_slots: None -> pix_to_face [N,H,W,faces_per_pixel] exactly like the
+        reference; 1 -> only the nearest-face plane [N,H,W,1] is written to HBM (all the
+        reference's callers read: `pix_to_face[..., 0]` loss_utils.py:214, `[..., :1]` :431).
+        The mask always blends the faces_per_pixel nearest faces."""
         super().__init__()
         self.img_size = img_size
+        self.pix_to_face_slots = pix_to_face_slots
         self.faces_per_pixel = faces_per_pixel          # nmr.py:158
         self.sigma = sigma                              # nmr.py:153
         self.gamma = gamma
@@ -49,7 +54,8 @@ class NeuralRenderer(torch.nn.Module):
             self.mask_only = True
             masks, pix_to_face = ops.sil_render(vertices, faces, cams, self.img_size,
                                                 K=self.faces_per_pixel, blur=self.blur_radius,
-                                                sigma=self.sigma, offset_z=self.offset_z)
+                                                sigma=self.sigma, offset_z=self.offset_z,
+                                                k_out=self.pix_to_face_slots)
             return masks, pix_to_face
         self.mask_only = False
         if not atlas:

@@ -70,20 +70,20 @@ def project(verts, cams, offset_z=0.0):
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, faces, cams, img_size, K, blur, sigma, offset_z):
+    def forward(ctx, verts, faces, cams, img_size, K, blur, sigma, offset_z, k_out):
         _lib.require_gpu(verts, faces, cams)
         v, c = _f32c(verts), _f32c(cams)
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
         mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
-        p2f = torch.empty((N, H, H, K), dtype=torch.int64, device=v.device)
+        p2f = torch.empty((N, H, H, k_out), dtype=torch.int64, device=v.device)
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
-                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, float(blur), float(sigma),
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
                 float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
                 _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_sil_forward")
         ctx.save_for_backward(v, f, c, mask, kth)
@@ -100,7 +100,7 @@ class _SilRender(torch.autograd.Function):
         N, V, _ = v.shape
         F = f.shape[1]
         if gmask is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
@@ -110,15 +110,18 @@ class _SilRender(torch.autograd.Function):
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
                 V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
                 _lib.cur_stream(v.device)), "acfm_sil_backward")
-        return gv, None, gc, None, None, None, None, None
+        return gv, None, gc, None, None, None, None, None, None
 
 
-def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0):
-    """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,K] i64).
+def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0,
+               k_out=None):
+    """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,k_out] i64), k_out = K (default,
+    what PyTorch3D returns) or 1 (nearest-face plane only; K faces are still blended).
     The visible-vertex bitmap the raster kernel produces on the side (vertices of every
     nearest face, = what bds_loss / optical_flow_loss derive from pix_to_face[..., 0]) rides
     along on the pix_to_face tensor object as `._acfm_vis`."""
-    mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z)
+    mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z,
+                                      K if k_out is None else int(k_out))
     p2f._acfm_vis = vis
     return mask, p2f
 

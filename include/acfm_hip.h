@@ -92,16 +92,19 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
  * proj_fn -> y flip -> view (R=diag(-1,1,1), T=(0,0,2.732)) -> PyTorch3D
  * rasterize_meshes(K, blur_radius, bin_size=None) -> sigmoid_alpha_blend(sigma).
  *   verts_world [N,V,3] f32, faces [N,F,3] i64, cams [N,7] f32
- *   -> mask [N,H,H] f32, pix_to_face [N,H,H,K] i64 (packed ids, ascending depth, -1 empty)
+ *   -> mask [N,H,H] f32, pix_to_face [N,H,H,k_out] i64 (packed ids, ascending depth, -1 empty)
+ *      k_out = K: every kept face, as PyTorch3D returns them; k_out = 1: only the nearest-face
+ *      plane (the K faces are still found and blended; it is the one slot the reference's
+ *      callers read, loss_utils.py:214,431, and saves 8*(K-1) bytes per pixel of HBM writes)
  *   -> kth [N,H,H] u64 (optional, NULL to skip): state for acfm_sil_backward -- the
  *      (depth bits << 32 | face) key of the K-th kept face where K faces were kept, else ~0
  *   -> vis [N,V] u8 (optional): 1 for every vertex of a face that is nearest in some pixel,
  *      i.e. the visible-vertex set of loss_utils.bds_loss (:214-224), fused into the raster
  * K in {2,4,8,10,20,32}. */
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N,
-                     int V, int F, int H, int K, float blur_radius, float sigma, float offset_z,
-                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* ws,
-                     size_t ws_bytes, void* stream);
+                     int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
+                     float offset_z, float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
