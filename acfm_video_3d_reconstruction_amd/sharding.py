@@ -60,14 +60,19 @@ class SharedGradReducer:
         if n_extra:
             flat[o:o + n_extra].copy_(extra_scalars.reshape(-1))
         if world > 1:
+            # gloo (CPU rehearsal of the multi-rank path) moves device buffers through the host
+            staged = flat.is_cuda and dist.get_backend(self.group) == "gloo"
+            buf = flat.cpu() if staged else flat
             if self.deterministic:
-                parts = [torch.empty_like(flat) for _ in range(world)]
-                dist.all_gather(parts, flat, group=self.group)
-                flat.zero_()
+                parts = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(parts, buf, group=self.group)
+                buf.zero_()
                 for part in parts:
-                    flat.add_(part)
+                    buf.add_(part)
             else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if staged:
+                flat.copy_(buf)
         if self.average:
             flat[:self.numel].div_(world)
         o = 0

@@ -76,12 +76,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # ACFM_DIST_BACKEND=gloo + ACFM_ALL_RANKS_ON_GPU0=1: rehearsal of the multi-rank control flow
+    # on a one-GPU box (collectives through the host); the real runs use nccl (= RCCL over xGMI)
+    backend = os.environ.get("ACFM_DIST_BACKEND", "nccl")
+    if os.environ.get("ACFM_ALL_RANKS_ON_GPU0") == "1":
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from acfm_video_3d_reconstruction_amd import _lib
     from acfm_video_3d_reconstruction_amd.deform import DeformSolver
@@ -158,7 +166,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
