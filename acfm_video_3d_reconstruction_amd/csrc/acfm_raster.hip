@@ -28,7 +28,7 @@ namespace acfm {
 
 constexpr int TILE = 16;      // pixels per tile side (PyTorch3D's auto bin size at 128/256)
 constexpr int TPB = 256;      // threads per workgroup = TILE*TILE
-constexpr int CAP = 512;      // LDS candidate-list capacity (walked early when it could overflow)
+constexpr int CAP = 384;      // LDS candidate-list capacity (walked early when it could overflow)
 constexpr unsigned long long KEY_NONE = ~0ull;
 constexpr int SETUP_LDS_TILES = 4096;  // tile counters kept in LDS up to 1024x1024 images
 
@@ -414,6 +414,26 @@ __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& o
   v[vi.x] = 1; v[vi.y] = 1; v[vi.z] = 1;
 }
 
+// Bubble-through insertion of (x, xq) into the sorted register list, four slots at a time.
+// `lim` (wave-uniform) bounds the number of faces any lane of the wave can hold so far: slots
+// at or beyond it are still empty in every lane, so those compare-exchanges are skipped with
+// scalar branches while every register index stays a compile-time constant.
+template <int K, int LO>
+__device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], float (&q)[K],
+                                              unsigned long long& x, float& xq, int lim) {
+#pragma unroll
+  for (int k = LO; k < (LO + 4 < K ? LO + 4 : K); ++k) {
+    const bool sw = x < key[k];
+    const unsigned long long tk = key[k];
+    const float tq = q[k];
+    key[k] = sw ? x : tk; x = sw ? tk : x;
+    q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
+  }
+  if constexpr (LO + 4 < K) {
+    if (lim > LO + 4) bubble_insert<K, LO + 4>(key, q, x, xq, lim);
+  }
+}
+
 template <int K, bool CLIP, bool TEX>
 __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
@@ -492,6 +512,7 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
     float q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
+    int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
     bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
       walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
         // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list
@@ -508,15 +529,9 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
         if (!live) return;
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
         float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const bool sw = x < key[k];
-          const unsigned long long tk = key[k];
-          const float tq = q[k];
-          key[k] = sw ? x : tk; x = sw ? tk : x;
-          q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
-        }
+        bubble_insert<K, 0>(key, q, x, xq, __builtin_amdgcn_readfirstlane(seen + ord + 1));
       });
+      seen += list_n;
     });
     if (!t.valid) return;
     float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
