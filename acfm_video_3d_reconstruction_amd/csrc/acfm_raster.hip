@@ -28,7 +28,7 @@ namespace acfm {
 
 constexpr int TILE = 16;      // pixels per tile side (PyTorch3D's auto bin size at 128/256)
 constexpr int TPB = 256;      // threads per workgroup = TILE*TILE
-constexpr int CAP = 384;      // LDS candidate-list capacity (walked early when it could overflow)
+constexpr int CAP = 320;      // LDS candidate-list capacity (walked early when it could overflow)
 constexpr unsigned long long KEY_NONE = ~0ull;
 constexpr int SETUP_LDS_TILES = 4096;  // tile counters kept in LDS up to 1024x1024 images
 
@@ -209,8 +209,10 @@ __device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
   t.n = n;
   t.tid = threadIdx.x; t.wv = t.tid >> 6; t.lane = t.tid & 63;
   const int ty = tl / tiles, tx = tl % tiles;
-  t.yi = ty * TILE + (t.wv >> 1) * 8 + (t.lane >> 3);
-  t.xi = tx * TILE + (t.wv & 1) * 8 + (t.lane & 7);
+  // wave = 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row)
+  const int grp = t.lane >> 4, j = t.lane & 15;
+  t.yi = ty * TILE + (t.wv >> 1) * 8 + (grp >> 1) * 4 + (j >> 2);
+  t.xi = tx * TILE + (t.wv & 1) * 8 + (grp & 1) * 4 + (j & 3);
   t.valid = (t.yi < H) && (t.xi < H);
   t.yf = pix_to_ndc(H - 1 - t.yi, H);
   t.xf = pix_to_ndc(H - 1 - t.xi, H);
@@ -225,7 +227,7 @@ struct CandList {
   float4 box[CAP], a[CAP], b[CAP];
   float2 c[CAP];    // (z2, area)
   int fid[CAP];
-  unsigned short sub[4][CAP];  // per-wave: candidates whose box meets the wave's 8x8 block
+  unsigned short sub[16][CAP]; // per 16-lane group (4 per wave): candidates meeting its 4x4 pixels
   int wcnt[2][4];
 };
 
@@ -241,41 +243,61 @@ __device__ __forceinline__ Cand load_cand(const CandList& L, int i) {
   return r;
 }
 
-// Second-level cull + walk, per wave: (A) 64 candidates at a time, lane i tests candidate i
-// against the wave's own 8x8 pixel block and the survivors are compacted (ballot) into the
-// wave's sub-list; (B) the sub-list is walked with the next record prefetched from LDS while
-// the current one is processed.  body(cand, in_box, ordinal) runs for every lane; in_box is
-// the per-pixel box test, ordinal the wave-uniform position in the sub-list.
+// Second-level cull + walk.  A wave covers 8x8 pixels as four 4x4 blocks, one per 16-lane
+// group.  (A) 64 candidates at a time, lane i tests candidate i against each of the four blocks;
+// the survivors are compacted (one ballot per group) into that group's own sub-list.  (B) the
+// four groups then walk THEIR OWN lists side by side -- in one iteration the groups work on
+// four different faces -- which keeps more lanes busy than walking the union of the lists
+// (a 4x4 block meets ~25 faces, the 8x8 block ~41).  The next record is prefetched from LDS
+// while the current one is processed.  body(cand, in_box, ordinal) runs for every lane;
+// in_box = the lane has a face this iteration and its pixel is inside the face's box.
 template <class Body>
 __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int list_n, Body&& body) {
-  // extent of this wave's block (pixel centres)
   const int by = (t.yi & ~7), bx = (t.xi & ~7);
-  const float w_xmax = pix_to_ndc(H - 1 - bx, H), w_xmin = pix_to_ndc(H - 1 - (bx + 7), H);
-  const float w_ymax = pix_to_ndc(H - 1 - by, H), w_ymin = pix_to_ndc(H - 1 - (by + 7), H);
-  unsigned short* sub = L.sub[t.wv];
-  int sub_n = 0;
+  const int grp = t.lane >> 4;
+  // NDC extents (pixel centres) of the four 4x4 blocks: x by column pair, y by row pair
+  const float xa0 = pix_to_ndc(H - 1 - bx, H), xi0 = pix_to_ndc(H - 1 - (bx + 3), H);
+  const float xa1 = pix_to_ndc(H - 1 - (bx + 4), H), xi1 = pix_to_ndc(H - 1 - (bx + 7), H);
+  const float ya0 = pix_to_ndc(H - 1 - by, H), yi0 = pix_to_ndc(H - 1 - (by + 3), H);
+  const float ya1 = pix_to_ndc(H - 1 - (by + 4), H), yi1 = pix_to_ndc(H - 1 - (by + 7), H);
+  unsigned short* sub0 = L.sub[t.wv * 4];
+  int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  const unsigned long long lt = (1ull << t.lane) - 1ull;
   for (int base = 0; base < list_n; base += 64) {
     const int c = base + t.lane;
-    bool hit = false;
+    bool hx0 = false, hx1 = false, hy0 = false, hy1 = false;
     if (c < list_n) {
       const float4 b = L.box[c];
-      hit = !((w_xmin > b.y) | (w_xmax < b.x) | (w_ymin > b.w) | (w_ymax < b.z));
+      hx0 = !((xi0 > b.y) | (xa0 < b.x)); hx1 = !((xi1 > b.y) | (xa1 < b.x));
+      hy0 = !((yi0 > b.w) | (ya0 < b.z)); hy1 = !((yi1 > b.w) | (ya1 < b.z));
     }
-    const unsigned long long bal = __ballot(hit);
-    if (hit) sub[sub_n + __popcll(bal & ((1ull << t.lane) - 1ull))] = (unsigned short)c;
-    sub_n += __popcll(bal);
+    const unsigned long long b0 = __ballot(hx0 & hy0), b1 = __ballot(hx1 & hy0);
+    const unsigned long long b2 = __ballot(hx0 & hy1), b3 = __ballot(hx1 & hy1);
+    if (hx0 & hy0) sub0[0 * CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
+    if (hx1 & hy0) sub0[1 * CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
+    if (hx0 & hy1) sub0[2 * CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
+    if (hx1 & hy1) sub0[3 * CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+    n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
   }
-  if (sub_n == 0) return;
+  const int n_max = max(max(n0, n1), max(n2, n3));
+  if (n_max == 0) return;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  Cand nxt = load_cand(L, sub[0]);
-  int i2 = sub[min(1, sub_n - 1)];
-  for (int i = 0; i < sub_n; ++i) {
+  const int my_n = (grp == 0) ? n0 : (grp == 1) ? n1 : (grp == 2) ? n2 : n3;
+  const unsigned short* sub = sub0 + grp * CAP;
+  // a group that has run out of faces (or has none) keeps loading its last (or the tile's
+  // first) record: harmless, the lanes are masked by `have`
+  const int last = max(my_n - 1, 0);
+  Cand nxt = load_cand(L, my_n > 0 ? sub[0] : 0);
+  int i2 = my_n > 0 ? sub[min(1, last)] : 0;
+  for (int i = 0; i < n_max; ++i) {
     const Cand cur = nxt;
     nxt = load_cand(L, i2);
-    i2 = sub[min(i + 2, sub_n - 1)];
-    const bool in_box = !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
+    i2 = my_n > 0 ? sub[min(i + 2, last)] : 0;
+    const bool have = i < my_n;
+    const bool in_box = have &&
+        !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
     body(cur, in_box, i);
   }
 }
@@ -558,19 +580,17 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
 }
 
 // ------------------------------------------------------------------------------- backward
-// wave64 sum on GFX9 DPP: row shifts inside each row of 16, then row broadcasts; the total
-// lands in lane 63 and is returned wave-uniform.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define ACFM_DPP_ADD(ctrl, rmask) \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
-  ACFM_DPP_ADD(0x111, 0xf);  // row_shr:1
-  ACFM_DPP_ADD(0x112, 0xf);  // row_shr:2
-  ACFM_DPP_ADD(0x114, 0xf);  // row_shr:4
-  ACFM_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row total
-  ACFM_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-  ACFM_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+// Sum over the 16 lanes of a DPP row (= one 4x4 pixel block): four row shifts, the total lands
+// in lane 15 of the row.
+__device__ __forceinline__ float row_sum_dpp(float v) {
+#define ACFM_DPP_ADD(ctrl) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+  ACFM_DPP_ADD(0x111);  // row_shr:1
+  ACFM_DPP_ADD(0x112);  // row_shr:2
+  ACFM_DPP_ADD(0x114);  // row_shr:4
+  ACFM_DPP_ADD(0x118);  // row_shr:8
 #undef ACFM_DPP_ADD
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return v;
 }
 
 // PointLineDistanceBackward with the clamped t held constant
@@ -653,14 +673,19 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
           g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_;
         }
       }
-      g0x = wave_sum_dpp(g0x); g0y = wave_sum_dpp(g0y);
-      g1x = wave_sum_dpp(g1x); g1y = wave_sum_dpp(g1y);
-      g2x = wave_sum_dpp(g2x); g2y = wave_sum_dpp(g2y);
-      if (t.lane == 0) {
+      // the 16 lanes of a row share the face: sum their contributions, lane 15 of the row adds
+      g0x = row_sum_dpp(g0x); g0y = row_sum_dpp(g0y);
+      g1x = row_sum_dpp(g1x); g1y = row_sum_dpp(g1y);
+      g2x = row_sum_dpp(g2x); g2y = row_sum_dpp(g2y);
+      // (a row without a face this iteration, or without members, sums to exact zeros)
+      if ((t.lane & 15) == 15) {
         const int4 vi = s_vidx[cd.idx];
-        atomicAdd(&s_g[2 * vi.x], g0x); atomicAdd(&s_g[2 * vi.x + 1], g0y);
-        atomicAdd(&s_g[2 * vi.y], g1x); atomicAdd(&s_g[2 * vi.y + 1], g1y);
-        atomicAdd(&s_g[2 * vi.z], g2x); atomicAdd(&s_g[2 * vi.z + 1], g2y);
+        if (g0x != 0.f) atomicAdd(&s_g[2 * vi.x], g0x);
+        if (g0y != 0.f) atomicAdd(&s_g[2 * vi.x + 1], g0y);
+        if (g1x != 0.f) atomicAdd(&s_g[2 * vi.y], g1x);
+        if (g1y != 0.f) atomicAdd(&s_g[2 * vi.y + 1], g1y);
+        if (g2x != 0.f) atomicAdd(&s_g[2 * vi.z], g2x);
+        if (g2y != 0.f) atomicAdd(&s_g[2 * vi.z + 1], g2y);
       }
     });
   });
