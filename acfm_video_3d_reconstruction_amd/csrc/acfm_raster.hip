@@ -351,7 +351,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
   }
 }
 
-struct Hit { float pz, sd, c0, c1, d01, d02, d12; };
+struct Hit { float pz, sd, c0, c1, c2, d01, d02, d12; };
 
 // One pixel against one face, split in two stages so callers can drop a face after the cheap
 // half.  Every rejection of the oracle (oracle_rasterize) is a pure filter, so evaluating
@@ -377,7 +377,7 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
   }
   const float pz = c0 * z0 + c1 * z1 + c2 * z2;
   inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-  h.pz = pz; h.c0 = c0; h.c1 = c1;
+  h.pz = pz; h.c0 = c0; h.c1 = c1; h.c2 = c2;
   return !(pz < 0.0f);
 }
 
@@ -422,6 +422,7 @@ struct FwdOut {
   uint8_t* vis;              // optional: [N,V] vertices of every nearest face
   int V;
   // texture branch (TEX)
+  const float* vrgb;         // optional [N,V,3]: per-vertex colours instead of an atlas (viz)
   const float* atlas;        // [N,F,R,R,3]
   float* imgs;               // [N,3,H,H]
   float* sil;                // [N,H,H]
@@ -478,14 +479,14 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
 
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
-    float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f;
+    float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
     bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
       walk_wave(L, t, H, list_n, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
         Hit h;
         if (!test_face<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
         const unsigned long long key = make_key(h.pz, cd.fid);
-        if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; }
+        if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
       });
     });
     if (!t.valid) return;
@@ -517,10 +518,24 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
         const float wnum = prob * expf((z_inv - z_inv_max) / out.gamma);
         const float delta = fmaxf(expf((eps - z_inv_max) / out.gamma), eps);
         const float den = wnum + delta;
-        const float* tx3 = out.atlas + ti * 3;
-        img[0] = (wnum * tx3[0] + delta * 0.0f) / den;
-        img[HW] = (wnum * tx3[1] + delta * 0.0f) / den;
-        img[2 * HW] = (wnum * tx3[2] + delta * 0.0f) / den;
+        float cr, cg, cb;
+        if (out.vrgb) {
+          // Textures(verts_rgb) (nmr.py:177-179): barycentric interpolation of the face's vertex colours
+          const int4 vi = ws.vidx[(size_t)n * F + f];
+          const float* c0 = out.vrgb + ((size_t)n * out.V + vi.x) * 3;
+          const float* c1 = out.vrgb + ((size_t)n * out.V + vi.y) * 3;
+          const float* c2 = out.vrgb + ((size_t)n * out.V + vi.z) * 3;
+          const float b2 = bestb2;
+          cr = bestb0 * c0[0] + bestb1 * c1[0] + b2 * c2[0];
+          cg = bestb0 * c0[1] + bestb1 * c1[1] + b2 * c2[1];
+          cb = bestb0 * c0[2] + bestb1 * c1[2] + b2 * c2[2];
+        } else {
+          const float* tx3 = out.atlas + ti * 3;
+          cr = tx3[0]; cg = tx3[1]; cb = tx3[2];
+        }
+        img[0] = (wnum * cr + delta * 0.0f) / den;
+        img[HW] = (wnum * cg + delta * 0.0f) / den;
+        img[2 * HW] = (wnum * cb + delta * 0.0f) / den;
         out.sil[t.pix] = 1.0f - (1.0f - prob);
         out.tidx[t.pix] = (int32_t)ti;
       }
@@ -1023,6 +1038,30 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
+  ProfScope ps(ACFM_PROF_TEX_FWD, st);
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F, H,
+                     0.f, sigma, out);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
+                              const float* verts_rgb, int N, int V, int F, int H, float sigma, float gamma,
+                              float offset_z, float* imgs, float* sil, int64_t* pix_to_face, void* wsp,
+                              size_t ws_bytes, void* stream) {
+  if (!verts_world || !faces || !cams || !verts_rgb || !imgs || !sil || !pix_to_face || !wsp) return ACFM_E_BADARG;
+  if (bad_dims(N, V, F, H) || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  if (ws.bytes + sizeof(int32_t) * (size_t)N * H * H > ws_bytes) return ACFM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
+  if (rc) return rc;
+  FwdOut out = {};
+  out.dbg = g_dbg;
+  out.p2f = pix_to_face;
+  out.vrgb = verts_rgb; out.V = V;
+  out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
+  out.atlas = verts_rgb;  // never dereferenced when vrgb is set
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
   hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F, H,
                      0.f, sigma, out);

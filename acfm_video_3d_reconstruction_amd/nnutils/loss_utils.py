@@ -226,6 +226,24 @@ class PerceptualTextureLoss_v2(object):
                                   "the MI355X hot path; plug the reference's module in unchanged")
 
 
+class TexCycle(nn.Module):
+    """loss_utils.py:386-416 (exported, never called by main.py): the learned texture flow of a
+    face should average to the face's projected position, on visible faces only."""
+
+    def __init__(self, im_size=256, nf=1280, eps=1e-12):
+        super(TexCycle, self).__init__()
+
+    def forward(self, flow, prob, aggr_info):
+        nb, nf, nr, _, _ = flow.size()
+        avg_flow = torch.mean(flow.view(nb, nf, -1, 2), dim=2)
+        mask = torch.zeros(avg_flow.size(), device=avg_flow.device)
+        for cnt in range(nb):
+            fids = torch.unique(aggr_info[cnt]).long()
+            mask[cnt, fids[fids >= 0], :] = 1
+        loss = torch.nn.MSELoss()(avg_flow * mask, prob * mask)
+        return loss, avg_flow[0, 0:10, :]
+
+
 def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True):
     """loss_utils.py:419-474.  meshes [b,t,V,3], faces [b,t,F,3], cams [b*t,7],
     flows [b,t,H,W,2]; renderer: an OF_NeuralRenderer-like object (proj_fn + __call__)."""

@@ -58,9 +58,11 @@ class NeuralRenderer(torch.nn.Module):
                                                 k_out=self.pix_to_face_slots)
             return masks, pix_to_face
         self.mask_only = False
-        if not atlas:
-            raise NotImplementedError("per-vertex RGB textures (atlas=False, nmr.py:177-179) are a "
-                                      "visualisation-only path and are not built yet")
+        if not atlas:  # nmr.py:177-179: Textures(verts_rgb), visualisation only (no gradients)
+            if textures.ndim == 2:
+                textures = textures[None]
+            return ops.vertex_color_render(vertices, faces, cams, textures.to(vertices.device),
+                                           self.img_size, sigma=1e-4, gamma=1e-4, offset_z=self.offset_z)
         imgs, sil, pix_to_face = ops.tex_render(vertices, faces, cams, textures.to(vertices.device),
                                                 self.img_size, sigma=1e-4, gamma=1e-4,
                                                 offset_z=self.offset_z)

@@ -195,6 +195,29 @@ def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offs
     return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z)
 
 
+def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
+    """atlas=False path (per-vertex RGB, visualisation): forward only, no gradients."""
+    _lib.require_gpu(verts, faces, cams, verts_rgb)
+    v, c, col = _f32c(verts), _f32c(cams), _f32c(verts_rgb)
+    N, V, _ = v.shape
+    f = expand_faces(faces, N)
+    F, H = f.shape[1], int(img_size)
+    if col.dim() == 2:
+        col = col[None]
+    col = col.expand(N, V, 3).contiguous()
+    imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
+    sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+    p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+    nb = _lib.lib().acfm_raster_workspace_bytes(N, V, F, H) + 4 * N * H * H
+    ws = torch.empty(nb, dtype=torch.uint8, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.lib().acfm_vertex_color_forward(
+            _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(col), N, V, F, H, float(sigma), float(gamma),
+            float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f), _lib.ptr(ws), nb,
+            _lib.cur_stream(v.device)), "acfm_vertex_color_forward")
+    return imgs, sil, p2f
+
+
 # ------------------------------------------------------------------------------ mask losses
 class _MaskLosses(torch.autograd.Function):
     @staticmethod

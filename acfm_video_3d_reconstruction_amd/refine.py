@@ -1,0 +1,57 @@
+"""Test-time refinement of a clip: the post-processing Adam loop of
+multiframe/nnutils/predictor.py:287-349 (BASELINE.json configs[2], "multiframe camera+deform
+solve") on the MI355X kernels.
+
+Differences from the reference loop are formulation only: the reference re-factorises the
+CONSTANT 642x642 system `cholesky(A_augm)` inside every iteration (predictor.py:313-315); here
+P = M^-1 A^T is factorised once (deform.DeformSolver) and every iteration applies
+v = v_mean + P (delta).  Same losses, same weights, same optimiser (Adam, lr 5e-3)."""
+import torch
+
+from .nnutils import loss_utils
+
+
+def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
+                num_optim_iter=20, optimize_camera=False, mask_loss_wt=1.0, boundaries_reg_wt=1.0,
+                edt_reg_wt=0.1, bdt_reg_wt=0.1, of_loss_wt=0.0, optical_flows=None, of_renderer=None,
+                num_frames=2, lr=5e-3):
+    """delta_v_res [N,K_h,3] predicted handle offsets, cam_pred [N,7], masks [N,H,W],
+    edts_barrier [N,1,H,W], boundaries [N,P,3]; optional optical_flows [b,T,H,W,2].
+    Returns (pred_v, cam, delta, history of total losses)."""
+    delta = delta_v_res.clone().detach().requires_grad_(True)
+    params = [delta]
+    scale, trans, quat = cam_pred[:, :1], cam_pred[:, 1:3], cam_pred[:, 3:]
+    if optimize_camera:
+        scale, trans, quat = (x.clone().detach().requires_grad_(True) for x in (scale, trans, quat))
+        params += [scale, trans, quat]
+    opt = torch.optim.Adam(params, lr=lr)
+    cam = cam_pred.detach()
+    history = []
+    pred_v = None
+    for _ in range(num_optim_iter):
+        if optimize_camera:
+            cam = torch.cat([scale, trans, torch.nn.functional.normalize(quat, dim=-1)], dim=1)
+        pred_v = solver(delta)                                                    # predictor.py:310-315
+        mask_pred, pix_to_face = renderer(pred_v, faces, cam)                     # :317
+        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
+        mask_loss = l1.mean()                                                     # :318 (reduce=True)
+        pred_proj = renderer.project_points(pred_v, cam)                          # :319
+        edt_loss = edt.mean()                                                     # :320
+        bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
+        # the reference pairs bdt_reg_wt with the EDT term and edt_reg_wt with the boundary term (:322)
+        sil_cons = bdt_reg_wt * edt_loss + edt_reg_wt * bdt_loss
+        total = mask_loss_wt * mask_loss + boundaries_reg_wt * sil_cons           # :343-344
+        if of_loss_wt > 0 and optical_flows is not None:
+            b = optical_flows.shape[0]
+            masks_of = masks.reshape(b, num_frames, masks.shape[1], masks.shape[2])
+            pred_v_of = pred_v.reshape(b, num_frames, pred_v.shape[1], pred_v.shape[2])
+            faces_of = faces.reshape(b, num_frames, faces.shape[1], 3)
+            flows_f = torch.flip(optical_flows, dims=[1]) * masks_of[..., None]
+            of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v_of, faces_of, cam, flows_f,
+                                                               of_renderer, pix_to_face)   # :334-339
+            total = total + of_loss_wt * of_loss
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        history.append(float(total.detach()))
+    return pred_v.detach() if pred_v is not None else None, cam.detach(), delta.detach(), history

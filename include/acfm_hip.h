@@ -136,6 +136,13 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
                      const float* atlas, int N, int V, int F, int H, int R, float sigma,
                      float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
                      int32_t* texel_idx, void* ws, size_t ws_bytes, void* stream);
+/* NeuralRenderer.forward with atlas=False (multiframe/nnutils/nmr.py:177-179, used by
+ * utils/bird_vis.py for visualisation): Textures(verts_rgb) = barycentric interpolation of
+ * per-vertex colours verts_rgb [N,V,3]; forward only.  Workspace: raster workspace + 4*N*H*H. */
+int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
+                              const float* verts_rgb, int N, int V, int F, int H, float sigma,
+                              float gamma, float offset_z, float* imgs, float* sil,
+                              int64_t* pix_to_face, void* ws, size_t ws_bytes, void* stream);
 /* grad_imgs [N,3,H,H] -> grad_atlas [N,F,R,R,3] (zeroed here, then scatter-added).
  * Integer texel indexing sends no gradient to geometry. */
 int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R,

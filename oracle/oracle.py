@@ -229,6 +229,29 @@ def tex_render(verts, faces, cams, atlas, img_size, offset_z=0.0, sigma=1e-4, ga
     return np.ascontiguousarray(rgb.transpose(0, 3, 1, 2)), sil, p2f, tidx
 
 
+def vertex_color_render(verts, faces, cams, verts_rgb, img_size, offset_z=0.0):
+    """NeuralRenderer.forward with atlas=False (nmr.py:177-179): Textures(verts_rgb) =
+    barycentric (clipped, nmr.py:87-89) interpolation of vertex colours, same K=1 blend."""
+    N = verts.shape[0]
+    H = img_size
+    ndc = to_ndc(project(verts, cams, offset_z), flip_y=True)
+    fv = face_verts_of(ndc, faces)
+    p2f, zbuf, bary, dists = rasterize(fv, N, H, 1, 0.0, clip_bary=True)
+    faces = np.asarray(faces)
+    if faces.ndim == 2:
+        faces = np.broadcast_to(faces, (N,) + faces.shape)
+    F = faces.shape[1]
+    col = np.broadcast_to(np.asarray(verts_rgb, np.float32), (N, verts.shape[1], 3))
+    imgs = np.zeros((N, H, H, 3), np.float32)
+    for n in range(N):
+        f = p2f[n, ..., 0]
+        cov = f >= 0
+        tri = faces[n][(f[cov] - n * F)]
+        c = (bary[n, ..., 0, :][cov][:, :, None] * col[n][tri]).sum(1)
+        imgs[n][cov] = c
+    return np.ascontiguousarray(imgs.transpose(0, 3, 1, 2)), p2f
+
+
 def tex_render_backward_atlas(tidx, grad_imgs, atlas_shape):
     """d/d atlas of sum(imgs * grad_imgs): rgb = w * texel / (w + delta) with the blend
     weight w = prob >= 0.5 and delta = 1e-10, i.e. d rgb / d texel = 1 to fp32 precision;

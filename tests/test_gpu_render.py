@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import batch_verts, make_cams
+from helpers import batch_verts, make_cams  # noqa: F401
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -187,3 +187,46 @@ def test_silhouette_nearest_plane_only(meshes):
     b = torch.autograd.grad((m1 * g).sum(), [tv, tc])
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
+
+
+def test_vertex_color_render_atlas_false(meshes):
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _dev()
+    n, H = 2, 96
+    verts, f, cams = _setup(meshes, "cow", n, 61)
+    col = np.random.default_rng(62).uniform(0, 1, (n, verts.shape[1], 3)).astype(np.float32)
+    ref_img, ref_p2f = O.vertex_color_render(verts, f, cams, col, H)
+    imgs, sil, p2f = NeuralRenderer(H)(torch.from_numpy(verts).to(d), torch.from_numpy(f)[None].repeat(n, 1, 1).to(d),
+                                       torch.from_numpy(cams).to(d), textures=torch.from_numpy(col).to(d), atlas=False)
+    np.testing.assert_array_equal(p2f.cpu().numpy(), ref_p2f)
+    np.testing.assert_allclose(imgs.cpu().numpy(), ref_img, rtol=0, atol=2e-6)
+
+
+def test_refinement_loop_reduces_the_loss(meshes):
+    """BASELINE config 3: test-time refinement of handle offsets (+ cameras) on a horse clip
+    (predictor.py:287-349) drives the silhouette losses down."""
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.refine import refine_clip
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    from scipy.ndimage import distance_transform_edt
+    d = _dev()
+    rng = np.random.default_rng(71)
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    N, H, Kh = 8, 128, 16
+    cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
+    faces = torch.tensor(f, device=d)[None].repeat(N, 1, 1)
+    solver = DeformSolver(torch.tensor(v, device=d), faces[0], torch.tensor(fps_lbs_logits(v, Kh), device=d))
+    r = NeuralRenderer(H)
+    with torch.no_grad():
+        gt_delta = torch.tensor(rng.normal(0, 0.05, (N, Kh, 3)).astype(np.float32), device=d)
+        gt, _ = r(solver(gt_delta), faces, cams)
+        gt = (gt > 0.5).float()
+    gm = gt.cpu().numpy()
+    edt = torch.tensor(np.stack([distance_transform_edt(1 - m) for m in gm]).astype(np.float32)[:, None], device=d)
+    ys, xs = np.nonzero(gm[0] > 0.5)
+    bds = torch.zeros(N, 64, 3, device=d)                       # a few (invalid-flagged) boundary points
+    pred_v, cam, delta, hist = refine_clip(r, solver, torch.zeros(N, Kh, 3, device=d), cams, faces, gt, edt, bds,
+                                           num_optim_iter=25, optimize_camera=True)
+    assert len(hist) == 25 and hist[-1] < 0.8 * hist[0]
+    assert pred_v.shape == (N, v.shape[0], 3) and torch.isfinite(pred_v).all()
