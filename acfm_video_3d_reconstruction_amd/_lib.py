@@ -37,6 +37,9 @@ SIGNATURES = {
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_edt_workspace_bytes": (_sz, [_i, _i, _i]),
+    "acfm_edt": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "acfm_boundaries": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_visible_vertices": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_bds_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_bds_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -184,6 +184,24 @@ int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_
                            const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
                            void* stream);
 
+/* ---- on-device input preparation ----------------------------------------
+ * replaces the per-batch CPU work of ShapeTrainer.set_input (multiframe/main.py:365-377) and
+ * its device->host->device round trip of the masks.
+ * acfm_edt: scipy.ndimage.distance_transform_edt(1 - mask) / divisor for every mask of the batch
+ *   (multiframe/utils/image.py:94-102; divisor = 1 for norm=False, max(H,W) for norm=True):
+ *   Euclidean distance of every pixel to the nearest pixel with mask == 1 (0 on those pixels).
+ *   Exact integer squared distances, sqrt in fp64, one rounding to fp32.
+ *   mask [N,H,W] f32 (0/1) -> out [N,H,W] f32. */
+size_t acfm_edt_workspace_bytes(int N, int H, int W);
+int acfm_edt(const float* mask, int N, int H, int W, int divisor, float* out, void* ws, size_t ws_bytes,
+             void* stream);
+/* acfm_boundaries: skimage.segmentation.find_boundaries(mask) (mode='thick', connectivity=1) +
+ *   the point list of compute_boundaries (multiframe/utils/image.py:122-146): for every mask
+ *   the boundary pixels in row-major order as (x, y, valid) with x = (col/W - 0.5)*2,
+ *   y = (row/H - 0.5)*2; rows beyond the count are (-1, -1, 0) like the reference's padding.
+ *   mask [N,H,W] f32 -> out [N,cap,3] f32 (first min(count, cap) points), counts [N] i32. */
+int acfm_boundaries(const float* mask, int N, int H, int W, int cap, float* out, int* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

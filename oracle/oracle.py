@@ -479,3 +479,48 @@ def subdivide(verts, faces):
         f2.append((c, e1, e0))
         f3.append((e0, e1, e2))
     return new_v.astype(verts.dtype), np.array(f0 + f1 + f2 + f3, dtype=faces.dtype)
+
+
+# ----------------------------------------------------------------------------- input prep
+def compute_dt(mask, norm=True):
+    """multiframe/utils/image.py:94-102 verbatim semantics (scipy IS the reference here)."""
+    from scipy.ndimage import distance_transform_edt
+    dist = distance_transform_edt(1 - mask)
+    if norm:
+        dist = dist / max(mask.shape)
+    return dist
+
+
+def compute_dt_barrier(mask, k=50):
+    """multiframe/utils/image.py:105-116."""
+    from scipy.ndimage import distance_transform_edt
+    diff = (distance_transform_edt(1 - mask) - distance_transform_edt(mask)) / max(mask.shape)
+    return 1.0 / (1 + np.exp(k * -diff))
+
+
+def find_boundaries(m):
+    """skimage.segmentation.find_boundaries (0.18.1 pinned in environment.yml:192), mode='thick',
+    connectivity=1: grey dilation != grey erosion over the 4-neighbourhood cross; skimage is not
+    installed here, scipy.ndimage (what skimage calls underneath) is."""
+    from scipy.ndimage import generate_binary_structure, grey_dilation, grey_erosion
+    fp = generate_binary_structure(2, 1)
+    return grey_dilation(m, footprint=fp) != grey_erosion(m, footprint=fp)
+
+
+def compute_boundaries(masks):
+    """multiframe/utils/image.py:122-146."""
+    bds = [np.transpose(find_boundaries(m).nonzero()) for m in masks]
+    max_bd = max(bd.shape[0] for bd in bds)
+    out, flag = [], []
+    for bd in bds:
+        f = np.ones(max_bd)
+        f[bd.shape[0]:] = 0
+        flag.append(f)
+        b = np.zeros((max_bd, 2))
+        b[:bd.shape[0]] = bd
+        out.append(b)
+    out = np.array(out)
+    out[..., 0] = (out[..., 0] / masks.shape[1] - 0.5) * 2
+    out[..., 1] = (out[..., 1] / masks.shape[2] - 0.5) * 2
+    out = out[..., ::-1].copy()
+    return np.concatenate((out, np.array(flag)[:, :, None]), axis=-1).astype(np.float32)

@@ -122,3 +122,29 @@ def test_masked_texture_mse():
     (out * w.to(d)).sum().backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_on_device_edt_and_boundaries(meshes):
+    """set_input's scipy / skimage prep on the GPU, against scipy itself."""
+    from acfm_video_3d_reconstruction_amd import image_utils as IU
+    d = _d()
+    rng = np.random.default_rng(5)
+    H = 96
+    yy, xx = np.mgrid[:H, :H]
+    masks = np.stack([((yy - 40) ** 2 / 900.0 + (xx - 50) ** 2 / 400.0 < 1).astype(np.float32),
+                      (rng.uniform(size=(H, H)) > 0.97).astype(np.float32),
+                      np.zeros((H, H), np.float32),                       # no foreground at all
+                      np.ones((H, H), np.float32)])
+    masks[0, :3, :] = 1                                                     # touches the image border
+    tm = torch.from_numpy(masks).to(d)
+    for norm in (False, True):
+        ref = np.stack([O.compute_dt(m, norm=norm) for m in masks]).astype(np.float32)
+        np.testing.assert_array_equal(IU.compute_dt(tm, norm=norm).cpu().numpy(), ref)
+    refb = np.stack([O.compute_dt_barrier(m) for m in masks[:2]]).astype(np.float32)
+    np.testing.assert_allclose(IU.compute_dt_barrier(tm[:2]).cpu().numpy(), refb, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(IU.compute_boundaries(tm).cpu().numpy(), O.compute_boundaries(masks))
+    np.testing.assert_array_equal(IU.compute_dt(tm[0], norm=False).cpu().numpy(), ref_single(masks[0]))
+
+
+def ref_single(m):
+    return O.compute_dt(m, norm=False).astype(np.float32)
