@@ -202,8 +202,19 @@ def main():
         }
         ab = alg.get(dom, 0)
         ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+        # the committed measurement of the same workload (rocprofv3 --pmc, separate passes) is quoted
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            w = pm["workload"]
+            if (w["frames"], w["img"], w["K"]) == (N, H, 20) and dom in pm["kernels"]:
+                traffic = pm["kernels"][dom]["fetch_bytes"] + pm["kernels"][dom]["write_bytes"]
+                traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1 only)
