@@ -22,6 +22,8 @@ SIGNATURES = {
     "acfm_prof_name": (ctypes.c_char_p, [_i]),
     "acfm_project": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "acfm_deform_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_deform_apply_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                               _sz, _vp]),
@@ -72,6 +74,17 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _LIB = handle
     return _LIB
+
+
+PROF_NKERNELS = 24  # ACFM_PROF_NKERNELS
+
+
+def prof_collect():
+    """-> {kernel name: (total ms, launches)} since acfm_prof_enable(1) / the last collect."""
+    ms = (ctypes.c_float * PROF_NKERNELS)()
+    cnt = (ctypes.c_int * PROF_NKERNELS)()
+    check(lib().acfm_prof_collect(ms, cnt, PROF_NKERNELS), "acfm_prof_collect")
+    return {lib().acfm_prof_name(i).decode(): (ms[i], cnt[i]) for i in range(PROF_NKERNELS) if cnt[i]}
 
 
 def ptr(t):

@@ -80,7 +80,10 @@ class DeformSolver(nn.Module):
         """delta [N,K_h,3] handle offsets -> deformed verts [N,V,3] (delta = 0: the mean shape)."""
         mean = self.mean_v if mean_override is None else mean_override
         P = self.solve_matrix()
-        return mean[None] + torch.matmul(P[None], delta)
+        if delta.is_cuda:
+            from . import ops
+            return ops.deform_apply(mean, P, delta)   # f32 MFMA kernels (csrc/acfm_deform.hip)
+        return mean[None] + torch.matmul(P[None], delta)  # host tensors: CPU-side tests of the algebra
 
 
 def deform_reference_formula(lbs_logits, mean_v, delta, L):

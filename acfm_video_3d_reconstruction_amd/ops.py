@@ -67,6 +67,45 @@ def project(verts, cams, offset_z=0.0):
     return _Project.apply(verts, cams, offset_z)
 
 
+# ------------------------------------------------------------------------------ deformation
+class _DeformApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean_v, P, delta):
+        _lib.require_gpu(mean_v, P, delta)
+        m, p, d = _f32c(mean_v), _f32c(P), _f32c(delta)
+        N, Kh, _ = d.shape
+        V = m.shape[0]
+        if p.shape != (V, Kh):
+            raise ValueError("P must be [V,K_h] = [%d,%d], got %s" % (V, Kh, tuple(p.shape)))
+        out = torch.empty((N, V, 3), dtype=torch.float32, device=m.device)
+        with torch.cuda.device(m.device):
+            _lib.check(_lib.lib().acfm_deform_apply(_lib.ptr(m), _lib.ptr(p), _lib.ptr(d), N, V, Kh,
+                                                    _lib.ptr(out), _lib.cur_stream(m.device)),
+                       "acfm_deform_apply")
+        ctx.save_for_backward(p, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, d = ctx.saved_tensors
+        N, Kh, _ = d.shape
+        V = p.shape[0]
+        g = _f32c(g)
+        gm = torch.empty((V, 3), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
+        gd = torch.empty_like(d) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_deform_apply_backward(
+                _lib.ptr(p), _lib.ptr(d), _lib.ptr(g), N, V, Kh, _lib.ptr(gd), _lib.ptr(gm), _lib.ptr(gp),
+                _lib.cur_stream(g.device)), "acfm_deform_apply_backward")
+        return gm, gp, gd
+
+
+def deform_apply(mean_v, P, delta):
+    """verts[n] = mean_v + P @ delta[n]  (mean_v [V,3], P [V,K_h], delta [N,K_h,3])."""
+    return _DeformApply.apply(mean_v, P, delta)
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod

@@ -180,11 +180,11 @@ def main():
         step()
     fence()
     if rank == 0:
-        ms = (ctypes.c_float * 16)()
-        cnt = (ctypes.c_int * 16)()
-        _lib.check(lib.acfm_prof_collect(ms, cnt, 16), "acfm_prof_collect")
+        ms = (ctypes.c_float * 24)()
+        cnt = (ctypes.c_int * 24)()
+        _lib.check(lib.acfm_prof_collect(ms, cnt, 24), "acfm_prof_collect")
         lib.acfm_prof_enable(0)
-        for i in range(16):
+        for i in range(24):
             if cnt[i]:
                 kern[lib.acfm_prof_name(i).decode()] = dict(avg_us=1e3 * ms[i] / cnt[i], launches=cnt[i],
                                                             us_per_step=1e3 * ms[i] / a.steps)

@@ -65,7 +65,9 @@ const char* acfm_arch(void);         /* "gfx950" */
 #define ACFM_PROF_PROJECT 12
 #define ACFM_PROF_TEX_MSE 13
 #define ACFM_PROF_TEX_MSE_BWD 14
-#define ACFM_PROF_NKERNELS 16
+#define ACFM_PROF_DEFORM 15
+#define ACFM_PROF_DEFORM_BWD 16
+#define ACFM_PROF_NKERNELS 24
 #define ACFM_PROF_RING 8192
 int acfm_prof_enable(int on);
 int acfm_prof_collect(float* ms_host, int* count_host, int n);
@@ -81,6 +83,18 @@ int acfm_project(const float* verts, const float* cams, int N, int V, float offs
 /* grad_proj [N,V,3] -> grad_verts [N,V,3] (may be NULL), grad_cams [N,7] (may be NULL) */
 int acfm_project_backward(const float* verts, const float* cams, const float* grad_proj, int N,
                           int V, float* grad_verts, float* grad_cams, void* stream);
+
+/* ---- template deformation --------------------------------------------------------------
+ * replaces the per-frame Cholesky solve of multiframe/main.py:586-609 (== predictor.py:260-276,
+ * 313-315, monocular/main.py:204-218) once P = (L^T L + A^T A)^-1 A^T [V,K_h] is known
+ * (factorised once per optimiser step, see deform.py):  verts[n] = mean_v + P delta[n].
+ *   mean_v [V,3], P [V,K_h], delta [N,K_h,3] -> verts [N,V,3]   (f32 MFMA 16x16x4)
+ * backward: grad_verts [N,V,3] -> grad_delta [N,K_h,3] = P^T g_n, grad_mean [V,3] = sum_n g_n,
+ *   grad_P [V,K_h] = sum_n g_n delta_n^T (each may be NULL). */
+int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, int N, int V, int Kh,
+                      float* verts, void* stream);
+int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
+                               int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
 
 /* ---- rasterisation workspace -------------------------------------------------------
  * Scratch of one render call of N meshes with V verts and F faces each at H x H pixels

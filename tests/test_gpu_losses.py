@@ -148,3 +148,33 @@ def test_on_device_edt_and_boundaries(meshes):
 
 def ref_single(m):
     return O.compute_dt(m, norm=False).astype(np.float32)
+
+
+def test_deform_apply_mfma_kernels(meshes):
+    """a8: verts = mean + P delta and its backward on the f32 matrix cores vs an fp64 evaluation."""
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    g = load_golden("solve")
+    for (N, Kh, V) in ((5, 16, 642), (64, 32, 642), (3, 7, 50)):
+        torch.manual_seed(N)
+        mean, P, delta = torch.randn(V, 3), torch.randn(V, Kh), 0.1 * torch.randn(N, Kh, 3)
+        w = torch.randn(N, V, 3)
+        a = [t.clone().to(d).requires_grad_(True) for t in (mean, P, delta)]
+        out = ops.deform_apply(*a)
+        (out * w.to(d)).sum().backward()
+        b = [t.clone().double().requires_grad_(True) for t in (mean, P, delta)]
+        ref = b[0][None] + torch.matmul(b[1][None], b[2])
+        (ref * w.double()).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # through the solver, against the reference's own fp32 output and the fp64 formula
+    v, f = torch.from_numpy(meshes["bird_v"]), torch.from_numpy(meshes["bird_f"])
+    logits, dl = torch.from_numpy(g["bird_k16_logits"]), torch.from_numpy(g["bird_k16_delta"])
+    solver = DeformSolver(v.to(d), f.to(d), logits.to(d))
+    out = solver(dl.to(d)).cpu()
+    truth = O.deform_solve(logits, v, dl, O.laplacian_cot(v.double(), f))
+    assert float((out.double() - truth).abs().max()) < 1e-4
+    assert np.abs(out.numpy() - g["bird_k16_pred_v"]).max() < 2e-4

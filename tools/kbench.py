@@ -59,12 +59,12 @@ def main():
     for _ in range(a.iters):
         run()
     torch.cuda.synchronize()
-    ms = (ctypes.c_float * 16)()
-    cnt = (ctypes.c_int * 16)()
-    _lib.check(lib.acfm_prof_collect(ms, cnt, 16), "collect")
+    ms = (ctypes.c_float * 24)()
+    cnt = (ctypes.c_int * 24)()
+    _lib.check(lib.acfm_prof_collect(ms, cnt, 24), "collect")
     lib.acfm_prof_enable(0)
     tot = 0.0
-    for i in range(16):
+    for i in range(24):
         if cnt[i]:
             per = 1e3 * ms[i] / a.iters
             tot += per
