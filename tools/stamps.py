@@ -41,7 +41,9 @@ print("start time percentiles (us): p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple
 for x in range(8):
     sel = xcc == x
     if sel.any():
-        print("xcc", x, "blocks", sel.sum(), "meshes", sorted(set(((np.nonzero(sel)[0] >> 3) // 256 * 8 + (np.nonzero(sel)[0] & 7)).tolist()))[:10],
-              "last end %.1f" % ((t1[sel].max() - t0.min()) / 100.0), "sum dur %.0f" % dur[sel].sum())
+        grp = sorted(set((np.nonzero(sel)[0] & 7).tolist()))
+        print("xcc", x, "blocks", sel.sum(), "block%8 groups", grp,
+              "last end %.1f" % ((t1[sel].max() - t0.min()) / 100.0), "sum dur %.0f" % dur[sel].sum(),
+              "idle-weighted util %.2f" % (dur[sel].sum() / (96 * (t1[sel].max() - t0[sel].min()) / 100.0)))
 order = np.argsort(-dur)[:8]
 print("heaviest blocks:", [(int(i), round(float(dur[i]), 1), round(float(start[i]), 1)) for i in order])
