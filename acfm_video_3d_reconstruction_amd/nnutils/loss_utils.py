@@ -59,13 +59,18 @@ def fused_silhouette_losses(mask_pred, mask_gt, edt, eps=1e-6):
     return out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]
 
 
+_CONJ_SIGN = (1.0, -1.0, -1.0, -1.0)
+
+
 def quat_conj(q):
-    return torch.cat([q[:, :, [0]], -1 * q[:, :, 1:4]], dim=-1)
+    """loss_utils.py:35-36: (w, x, y, z) -> (w, -x, -y, -z) on [B,N,4]."""
+    return q * q.new_tensor(_CONJ_SIGN)
 
 
 def quat2ang(q):
-    ang = 2 * torch.acos(torch.clamp(q[:, :, 0], min=-1 + 1E-6, max=1 - 1E-6))
-    return ang.unsqueeze(-1)
+    """loss_utils.py:39-42: rotation angle 2*acos(w), w clamped away from +-1; [B,N,4] -> [B,N,1]."""
+    w = q[..., 0].clamp(-1 + 1e-6, 1 - 1e-6)
+    return (2.0 * torch.acos(w))[..., None]
 
 
 hamilton_product = geom_utils.hamilton_product
@@ -171,11 +176,12 @@ def hinge_loss(loss, margin):
 
 def quat_loss_geodesic(q1, q2):
     """loss_utils.py:262-277."""
-    q1 = torch.unsqueeze(q1, 1)
-    q2 = torch.unsqueeze(q2, 1)
-    q2_conj = torch.cat([q2[:, :, [0]], -1 * q2[:, :, 1:4]], dim=-1)
-    q_rel = geom_utils.hamilton_product(q1, q2_conj)
-    return 1 - torch.abs(q_rel[:, :, 0])
+    # only the real part of q1 (x) conj(q2) is needed: w1 w2 + x1 x2 + y1 y2 + z1 z2 in the
+    # reference's operation order (products subtracted from the first with the conjugate's signs)
+    a0, a1, a2, a3 = q1.unbind(-1)
+    b0, b1, b2, b3 = q2[:, 0], -1 * q2[:, 1], -1 * q2[:, 2], -1 * q2[:, 3]
+    real = a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3
+    return (1 - real.abs())[:, None]
 
 
 def camera_loss(cam_pred, cam_gt, margin):
@@ -199,8 +205,7 @@ def triangle_loss(verts, edge2verts):
 
 def deform_l2reg(V):
     """loss_utils.py:322-327."""
-    V = V.view(-1, V.size(2))
-    return torch.mean(torch.norm(V, p=2, dim=1))
+    return V.reshape(-1, V.shape[2]).norm(p=2, dim=1).mean()
 
 
 def entropy_loss(A):
@@ -210,12 +215,10 @@ def entropy_loss(A):
 
 def kp_l2_loss(kp_pred, kp_gt, reduction='mean'):
     """loss_utils.py:341-356."""
-    vis = (kp_gt[:, :, 2] > 0).float()
-    loss = torch.nn.L1Loss(reduction='none')(kp_pred, kp_gt[:, :, :2]).sum(-1) * vis
-    loss = loss.mean(-1) / (vis.mean(-1) + 1e-4)
-    if reduction == 'mean':
-        return loss.mean()
-    return loss
+    visible = kp_gt[..., 2].gt(0).to(kp_pred.dtype)
+    per_kp = (kp_pred - kp_gt[..., :2]).abs().sum(-1) * visible          # L1, despite the name
+    per_img = per_kp.mean(-1) / (visible.mean(-1) + 1e-4)
+    return per_img.mean() if reduction == 'mean' else per_img
 
 
 class PerceptualTextureLoss_v2(object):
@@ -234,14 +237,13 @@ class TexCycle(nn.Module):
         super(TexCycle, self).__init__()
 
     def forward(self, flow, prob, aggr_info):
-        nb, nf, nr, _, _ = flow.size()
-        avg_flow = torch.mean(flow.view(nb, nf, -1, 2), dim=2)
-        mask = torch.zeros(avg_flow.size(), device=avg_flow.device)
-        for cnt in range(nb):
-            fids = torch.unique(aggr_info[cnt]).long()
-            mask[cnt, fids[fids >= 0], :] = 1
-        loss = torch.nn.MSELoss()(avg_flow * mask, prob * mask)
-        return loss, avg_flow[0, 0:10, :]
+        batch, n_faces = flow.shape[:2]
+        mean_flow = flow.reshape(batch, n_faces, -1, 2).mean(2)
+        seen = torch.zeros(batch, n_faces, 1, device=flow.device, dtype=flow.dtype)
+        for i in range(batch):
+            ids = aggr_info[i].reshape(-1).long()
+            seen[i, ids[ids >= 0].unique()] = 1
+        return F.mse_loss(mean_flow * seen, prob * seen), mean_flow[0, :10]
 
 
 def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True):
@@ -259,25 +261,23 @@ def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=
             pix_to_face = pix_to_face[..., :1]
         visible_vertices = ops.visible_vertices(pix_to_face, faces_bt, nv).reshape(b, t, nv)
 
-    pts = predicted_points[:, :, None, :2]
-    fl = flows.reshape(bt, H, W, -1).permute(0, 3, 1, 2)
-    samples_ofs_gt = F.grid_sample(fl, pts, align_corners=False, mode='nearest')
-    samples_ofs_gt = samples_ofs_gt[..., 0].permute(0, 2, 1).reshape(b, t, nv, -1)
-
-    predicted_points = pts.reshape(b, t, nv, -1)
-    predicted_points_ = W * (predicted_points + 1) / 2
-    of_pred = predicted_points_[:, :-1] - predicted_points_[:, 1:]
-
-    visible_vertices = (samples_ofs_gt.abs().sum(-1) != 0).bool() * visible_vertices.bool()
-    visible_vertices = visible_vertices.float()[:, 1:].detach()
-    samples_ofs_gt = visible_vertices[..., None] * samples_ofs_gt[:, 1:]
-    of_pred = visible_vertices[..., None] * of_pred
-    loss = torch.norm(samples_ofs_gt[..., 0] - of_pred[..., 0], p=1, dim=-1) + torch.norm(
-        samples_ofs_gt[..., 1] - of_pred[..., 1], p=1, dim=-1)
-    loss = loss / H / (visible_vertices.sum(-1) + 1)
-    if reduce:
-        loss = loss.sum()
-    return loss, of_pred, visible_vertices, predicted_points, samples_ofs_gt
+    xy = predicted_points[..., :2]                                            # [bt, V, 2] in [-1, 1]
+    # GT flow at each projected vertex: nearest pixel (:449-452)
+    flow_img = flows.reshape(bt, H, W, -1).permute(0, 3, 1, 2)
+    gt_flow = F.grid_sample(flow_img, xy[:, :, None, :], align_corners=False, mode='nearest')
+    gt_flow = gt_flow.squeeze(-1).transpose(1, 2).reshape(b, t, nv, -1)
+    # predicted flow: pixel displacement of the same vertex between frame k and k+1 (:455-459)
+    xy_bt = xy.reshape(b, t, nv, 2)
+    pix = W * (xy_bt + 1) / 2
+    flow_pred = pix[:, :-1] - pix[:, 1:]
+    # vertices that are visible AND land on a pixel with a non-zero GT flow, frames 1.. (:462-465)
+    keep = (gt_flow.abs().sum(-1) != 0) & visible_vertices.bool()
+    keep = keep[:, 1:].to(flow_pred.dtype).detach()
+    gt_kept = keep[..., None] * gt_flow[:, 1:]
+    flow_pred = keep[..., None] * flow_pred
+    loss = (gt_kept - flow_pred).abs().sum(dim=(-1, -2))                      # L1 over x and y (:468-469)
+    loss = loss / H / (keep.sum(-1) + 1)
+    return (loss.sum() if reduce else loss), flow_pred, keep, xy_bt, gt_kept
 
 
 class Optical_Flow_Loss(nn.Module):
