@@ -14,9 +14,13 @@ from .nnutils import loss_utils
 def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
                 num_optim_iter=20, optimize_camera=False, mask_loss_wt=1.0, boundaries_reg_wt=1.0,
                 edt_reg_wt=0.1, bdt_reg_wt=0.1, of_loss_wt=0.0, optical_flows=None, of_renderer=None,
-                num_frames=2, lr=5e-3):
+                num_frames=2, lr=5e-3, use_graph=False):
     """delta_v_res [N,K_h,3] predicted handle offsets, cam_pred [N,7], masks [N,H,W],
     edts_barrier [N,1,H,W], boundaries [N,P,3]; optional optical_flows [b,T,H,W,2].
+    use_graph=True captures one whole iteration (render, losses, backward, Adam update) into a
+    hipGraph after three eager iterations and replays it for the rest: the loop is launch-bound
+    (~30 short kernels per iteration) and every entry point is stream-ordered, so the replayed
+    iterations perform exactly the eager sequence of updates without returning to Python.
     Returns (pred_v, cam, delta, history of total losses)."""
     delta = delta_v_res.clone().detach().requires_grad_(True)
     params = [delta]
@@ -24,11 +28,14 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
     if optimize_camera:
         scale, trans, quat = (x.clone().detach().requires_grad_(True) for x in (scale, trans, quat))
         params += [scale, trans, quat]
-    opt = torch.optim.Adam(params, lr=lr)
-    cam = cam_pred.detach()
-    history = []
-    pred_v = None
-    for _ in range(num_optim_iter):
+    graphable = use_graph and delta.is_cuda
+    opt = torch.optim.Adam(params, lr=lr, capturable=graphable)
+    state = {"cam": cam_pred.detach(), "pred_v": None}
+    hist_buf = torch.zeros(max(num_optim_iter, 1), device=delta.device)
+    it_idx = torch.zeros((), dtype=torch.long, device=delta.device)
+
+    def iteration():
+        cam = state["cam"]
         if optimize_camera:
             cam = torch.cat([scale, trans, torch.nn.functional.normalize(quat, dim=-1)], dim=1)
         pred_v = solver(delta)                                                    # predictor.py:310-315
@@ -50,8 +57,31 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
             of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v_of, faces_of, cam, flows_f,
                                                                of_renderer, pix_to_face)   # :334-339
             total = total + of_loss_wt * of_loss
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)
         total.backward()
         opt.step()
-        history.append(float(total.detach()))
-    return pred_v.detach() if pred_v is not None else None, cam.detach(), delta.detach(), history
+        hist_buf.index_put_((it_idx,), total.detach())      # loss log stays on the device
+        it_idx.add_(1)
+        state["cam_out"], state["pred_v"] = cam.detach(), pred_v.detach()
+
+    n_eager = num_optim_iter if not graphable else min(3, num_optim_iter)
+    if graphable and num_optim_iter > n_eager:
+        side = torch.cuda.Stream(device=delta.device)
+        side.wait_stream(torch.cuda.current_stream(delta.device))
+        with torch.cuda.stream(side):
+            for _ in range(n_eager):
+                iteration()
+        torch.cuda.current_stream(delta.device).wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            iteration()
+        for _ in range(num_optim_iter - n_eager - 1):
+            graph.replay()
+    else:
+        for _ in range(num_optim_iter):
+            iteration()
+    history = hist_buf[:num_optim_iter].tolist()
+    pred_v = state["pred_v"]
+    return (pred_v.clone() if pred_v is not None else None), state.get("cam_out", state["cam"]).clone(), \
+        delta.detach().clone(), history

@@ -230,6 +230,14 @@ def test_refinement_loop_reduces_the_loss(meshes):
                                            num_optim_iter=25, optimize_camera=True)
     assert len(hist) == 25 and hist[-1] < 0.8 * hist[0]
     assert pred_v.shape == (N, v.shape[0], 3) and torch.isfinite(pred_v).all()
+    # the same loop with iterations 4..25 replayed from a hipGraph performs the same updates
+    pv2, cam2, delta2, hist2 = refine_clip(r, solver, torch.zeros(N, Kh, 3, device=d), cams, faces, gt, edt, bds,
+                                           num_optim_iter=25, optimize_camera=True, use_graph=True)
+    # (float-atomic summation order makes the two Adam trajectories drift apart slowly)
+    assert len(hist2) == 25 and min(hist2) > 0
+    np.testing.assert_allclose(hist2[:6], hist[:6], rtol=1e-3)
+    np.testing.assert_allclose(hist2, hist, rtol=5e-2)
+    assert float((pv2 - pred_v).abs().max()) < 2e-2
 
 
 def test_hip_graph_capture_and_replay(meshes):
