@@ -75,8 +75,8 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
         opt.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            iteration()
-        for _ in range(num_optim_iter - n_eager - 1):
+            iteration()                      # recorded, not executed
+        for _ in range(num_optim_iter - n_eager):
             graph.replay()
     else:
         for _ in range(num_optim_iter):
