@@ -53,6 +53,16 @@ def test_subdivided_template_many_binning_rounds(meshes):
     assert (p[..., 19] >= 0).sum() > 0                      # K-truncation exercised
 
 
+def test_config5_shape_512(meshes):
+    """BASELINE config 5 shape: subdivided template (5120 faces) @512^2 (fp32; the fp16 variant has
+    no reference semantics)."""
+    rng = np.random.default_rng(12)
+    v, f = O.subdivide(meshes["horse_v"], meshes["horse_f"])
+    verts = batch_verts(v.astype(np.float32), 1, rng, 0.003)
+    cams = make_cams(1, rng, extent=float(np.abs(v).max()))
+    _check_sil(verts, f.astype(np.int64), cams, 512)
+
+
 def test_whole_mesh_in_one_tile_list_overflow(meshes):
     """Tiny scale: all 1280 faces land in a couple of tiles -> the LDS candidate list is walked in
     several rounds and almost every pixel overflows K."""
