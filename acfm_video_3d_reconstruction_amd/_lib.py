@@ -39,6 +39,12 @@ SIGNATURES = {
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_cot_laplacian": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_laplacian_smoothing_state_floats": (_sz, [_i, _i]),
+    "acfm_laplacian_smoothing": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_laplacian_smoothing_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_edge_rigidity": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "acfm_edge_rigidity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_edt_workspace_bytes": (_sz, [_i, _i, _i]),
     "acfm_edt": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "acfm_boundaries": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),

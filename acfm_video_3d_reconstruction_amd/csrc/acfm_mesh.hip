@@ -1,0 +1,299 @@
+// Mesh priors of the hot path as fused gfx950 kernels:
+//   acfm_cot_laplacian            <- geom_utils.mesh_laplacian(mesh, 'cot')   (geom_utils.py:158-324)
+//   acfm_laplacian_smoothing{,_backward} <- pytorch3d.loss.mesh_laplacian_smoothing(meshes, 'cot' | 'uniform')
+//                                     (called at multiframe/main.py:699-704; semantics SURVEY App-A.7)
+//   acfm_edge_rigidity{,_backward} <- loss_utils.locally_rigid_fn            (loss_utils.py:150-164)
+// All take PACKED meshes (verts [P,3], faces / edges with packed vertex ids), i.e. any mix of
+// topologies.  The torch-op formulations launch 10-20 small kernels each (index_add, norm, ...);
+// here each is one or two passes with float atomics (results differ from a sequential sum in the
+// last bits only).
+#include "acfm_common.h"
+
+namespace acfm {
+
+constexpr int MTPB = 256;
+
+// cotangent weights / 4 of one face exactly as geom_utils.laplacian_cot (:277-298): side lengths,
+// Heron's area clamped at 1e-12 before the sqrt, cot = (b^2 + c^2 - a^2) / area / 4.
+struct FaceCot { float cota, cotb, cotc; };
+__device__ __forceinline__ FaceCot face_cot(const float* __restrict__ v, long i0, long i1, long i2) {
+  const float ax = v[3 * i0], ay = v[3 * i0 + 1], az = v[3 * i0 + 2];
+  const float bx = v[3 * i1], by = v[3 * i1 + 1], bz = v[3 * i1 + 2];
+  const float cx = v[3 * i2], cy = v[3 * i2 + 1], cz = v[3 * i2 + 2];
+  const float A = sqrtf((bx - cx) * (bx - cx) + (by - cy) * (by - cy) + (bz - cz) * (bz - cz));  // |v1 - v2|
+  const float B = sqrtf((ax - cx) * (ax - cx) + (ay - cy) * (ay - cy) + (az - cz) * (az - cz));  // |v0 - v2|
+  const float C = sqrtf((ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz));  // |v0 - v1|
+  const float s = 0.5f * (A + B + C);
+  const float area = sqrtf(fmaxf(s * (s - A) * (s - B) * (s - C), 1e-12f));
+  const float A2 = A * A, B2 = B * B, C2 = C * C;
+  FaceCot r;
+  r.cota = (B2 + C2 - A2) / area / 4.0f;   // weight of edge (v1, v2)
+  r.cotb = (A2 + C2 - B2) / area / 4.0f;   // weight of edge (v2, v0)
+  r.cotc = (A2 + B2 - C2) / area / 4.0f;   // weight of edge (v0, v1)
+  return r;
+}
+
+// ---- a9: dense L = W - diag(rowsum W) of ONE mesh, L pre-zeroed -----------------------------
+__global__ void k_cot_laplacian(const float* __restrict__ verts, const int64_t* __restrict__ faces, int V,
+                                int F, float* __restrict__ L) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const long i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) return;
+  const FaceCot c = face_cot(verts, i0, i1, i2);
+  const long e[3][2] = {{i1, i2}, {i2, i0}, {i0, i1}};
+  const float w[3] = {c.cota, c.cotb, c.cotc};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long i = e[k][0], j = e[k][1];
+    atomicAdd(&L[(size_t)i * V + j], w[k]);
+    atomicAdd(&L[(size_t)j * V + i], w[k]);
+    atomicAdd(&L[(size_t)i * V + i], -w[k]);
+    atomicAdd(&L[(size_t)j * V + j], -w[k]);
+  }
+}
+
+// ---- a15: Laplacian smoothing -----------------------------------------------------------------
+// pass 1 (per face): accumulate Wv[i] += w_ij v_j and rowsum[i] += w_ij for the six directed
+// pairs; cot weights are kept (wface) for the backward.  uniform: w = 1 per directed edge of
+// the UNIQUE edge list (pass 1 then runs over edges).
+__global__ void k_lap_accum_faces(const float* __restrict__ verts, const int64_t* __restrict__ faces, int P,
+                                  int F, float* __restrict__ Wv, float* __restrict__ rowsum,
+                                  float* __restrict__ wface) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const long i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= P || i1 >= P || i2 >= P) {
+    wface[3 * f] = 0.f; wface[3 * f + 1] = 0.f; wface[3 * f + 2] = 0.f;
+    return;
+  }
+  const FaceCot c = face_cot(verts, i0, i1, i2);
+  wface[3 * f] = c.cota; wface[3 * f + 1] = c.cotb; wface[3 * f + 2] = c.cotc;
+  const long e[3][2] = {{i1, i2}, {i2, i0}, {i0, i1}};
+  const float w[3] = {c.cota, c.cotb, c.cotc};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long i = e[k][0], j = e[k][1];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      atomicAdd(&Wv[3 * i + d], w[k] * verts[3 * j + d]);
+      atomicAdd(&Wv[3 * j + d], w[k] * verts[3 * i + d]);
+    }
+    atomicAdd(&rowsum[i], w[k]);
+    atomicAdd(&rowsum[j], w[k]);
+  }
+}
+
+__global__ void k_lap_accum_edges(const float* __restrict__ verts, const int64_t* __restrict__ edges, int P,
+                                  int E, float* __restrict__ Wv, float* __restrict__ rowsum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long i = edges[2 * e], j = edges[2 * e + 1];
+  if (i < 0 || j < 0 || i >= P || j >= P) return;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    atomicAdd(&Wv[3 * i + d], verts[3 * j + d]);
+    atomicAdd(&Wv[3 * j + d], verts[3 * i + d]);
+  }
+  atomicAdd(&rowsum[i], 1.0f);
+  atomicAdd(&rowsum[j], 1.0f);
+}
+
+// pass 2 (per vertex): lv = Wv * nw - v with nw = 1/rowsum (0 where rowsum <= 0);
+// loss += |lv| * vweight[v];  glv = vweight * lv / |lv| is stored for the backward.
+__global__ __launch_bounds__(MTPB) void k_lap_vertex(const float* __restrict__ verts,
+                                                     const float* __restrict__ Wv,
+                                                     const float* __restrict__ rowsum,
+                                                     const float* __restrict__ vweight, int P,
+                                                     float* __restrict__ glv, float* __restrict__ loss) {
+  __shared__ float s_red[4];
+  const int v = blockIdx.x * MTPB + threadIdx.x;
+  float contrib = 0.f;
+  if (v < P) {
+    const float rs = rowsum[v];
+    const float nw = rs > 0.f ? 1.0f / rs : 0.f;
+    const float lx = Wv[3 * v] * nw - verts[3 * v];
+    const float ly = Wv[3 * v + 1] * nw - verts[3 * v + 1];
+    const float lz = Wv[3 * v + 2] * nw - verts[3 * v + 2];
+    const float nrm = sqrtf(lx * lx + ly * ly + lz * lz);
+    const float w = vweight[v];
+    contrib = nrm * w;
+    const float inv = nrm > 0.f ? w / nrm : 0.f;   // torch: subgradient 0 at the origin
+    glv[3 * v] = lx * inv; glv[3 * v + 1] = ly * inv; glv[3 * v + 2] = lz * inv;
+  }
+  contrib = wave_sum(contrib);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+// backward: d loss / d v_j = sum_i w_ij nw_i glv_i - glv_j  (weights are constants)
+__global__ void k_lap_bwd_init(const float* __restrict__ glv, const float* __restrict__ gop, int P3,
+                               float* __restrict__ gv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P3) gv[i] = -gop[0] * glv[i];
+}
+__global__ void k_lap_bwd_faces(const int64_t* __restrict__ faces, const float* __restrict__ wface,
+                                const float* __restrict__ rowsum, const float* __restrict__ glv,
+                                const float* __restrict__ gop, int P, int F, float* __restrict__ gv) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const float go = gop[0];
+  const long i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= P || i1 >= P || i2 >= P) return;
+  const long e[3][2] = {{i1, i2}, {i2, i0}, {i0, i1}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long i = e[k][0], j = e[k][1];
+    const float w = go * wface[3 * f + k];
+    const float ni = rowsum[i] > 0.f ? 1.0f / rowsum[i] : 0.f, nj = rowsum[j] > 0.f ? 1.0f / rowsum[j] : 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      atomicAdd(&gv[3 * j + d], w * ni * glv[3 * i + d]);
+      atomicAdd(&gv[3 * i + d], w * nj * glv[3 * j + d]);
+    }
+  }
+}
+__global__ void k_lap_bwd_edges(const int64_t* __restrict__ edges, const float* __restrict__ rowsum,
+                                const float* __restrict__ glv, const float* __restrict__ gop, int P, int E,
+                                float* __restrict__ gv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float go = gop[0];
+  const long i = edges[2 * e], j = edges[2 * e + 1];
+  if (i < 0 || j < 0 || i >= P || j >= P) return;
+  const float ni = rowsum[i] > 0.f ? 1.0f / rowsum[i] : 0.f, nj = rowsum[j] > 0.f ? 1.0f / rowsum[j] : 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    atomicAdd(&gv[3 * j + d], go * ni * glv[3 * i + d]);
+    atomicAdd(&gv[3 * i + d], go * nj * glv[3 * j + d]);
+  }
+}
+
+// ---- a14: edge rigidity --------------------------------------------------------------------
+__global__ __launch_bounds__(MTPB) void k_rigid(const float* __restrict__ v, const int64_t* __restrict__ e,
+                                                const float* __restrict__ vt, const int64_t* __restrict__ et,
+                                                int E, float* __restrict__ loss) {
+  __shared__ float s_red[4];
+  const int i = blockIdx.x * MTPB + threadIdx.x;
+  float c = 0.f;
+  if (i < E) {
+    const long a = e[2 * i], b = e[2 * i + 1], at = et[2 * i], bt = et[2 * i + 1];
+    const float dx = v[3 * a] - v[3 * b], dy = v[3 * a + 1] - v[3 * b + 1], dz = v[3 * a + 2] - v[3 * b + 2];
+    const float tx = vt[3 * at] - vt[3 * bt], ty = vt[3 * at + 1] - vt[3 * bt + 1], tz = vt[3 * at + 2] - vt[3 * bt + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz) - sqrtf(tx * tx + ty * ty + tz * tz);
+    c = d * d;
+  }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+__global__ void k_rigid_bwd(const float* __restrict__ v, const int64_t* __restrict__ e,
+                            const float* __restrict__ vt, const int64_t* __restrict__ et, int E,
+                            const float* __restrict__ gop, float* __restrict__ gv, float* __restrict__ gvt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const float go = gop[0];
+  const long a = e[2 * i], b = e[2 * i + 1], at = et[2 * i], bt = et[2 * i + 1];
+  const float dx = v[3 * a] - v[3 * b], dy = v[3 * a + 1] - v[3 * b + 1], dz = v[3 * a + 2] - v[3 * b + 2];
+  const float tx = vt[3 * at] - vt[3 * bt], ty = vt[3 * at + 1] - vt[3 * bt + 1], tz = vt[3 * at + 2] - vt[3 * bt + 2];
+  const float ld = sqrtf(dx * dx + dy * dy + dz * dz), lt = sqrtf(tx * tx + ty * ty + tz * tz);
+  const float g = go * 2.0f * (ld - lt);
+  if (gv) {
+    const float s = ld > 0.f ? g / ld : 0.f;
+    atomicAdd(&gv[3 * a], s * dx); atomicAdd(&gv[3 * a + 1], s * dy); atomicAdd(&gv[3 * a + 2], s * dz);
+    atomicAdd(&gv[3 * b], -s * dx); atomicAdd(&gv[3 * b + 1], -s * dy); atomicAdd(&gv[3 * b + 2], -s * dz);
+  }
+  if (gvt) {
+    const float s = lt > 0.f ? -g / lt : 0.f;
+    atomicAdd(&gvt[3 * at], s * tx); atomicAdd(&gvt[3 * at + 1], s * ty); atomicAdd(&gvt[3 * at + 2], s * tz);
+    atomicAdd(&gvt[3 * bt], -s * tx); atomicAdd(&gvt[3 * bt + 1], -s * ty); atomicAdd(&gvt[3 * bt + 2], -s * tz);
+  }
+}
+
+static inline unsigned nblk(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace acfm
+
+using namespace acfm;
+
+extern "C" {
+
+int acfm_cot_laplacian(const float* verts, const int64_t* faces, int V, int F, float* L, void* stream) {
+  if (!verts || !faces || !L || V <= 0 || F <= 0) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(L, 0, sizeof(float) * (size_t)V * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  hipLaunchKernelGGL(k_cot_laplacian, dim3(nblk(F, 256)), dim3(256), 0, st, verts, faces, V, F, L);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+size_t acfm_laplacian_smoothing_state_floats(int P, int F) {
+  if (P <= 0 || F < 0) return 0;
+  return (size_t)7 * P + (size_t)3 * F;  // Wv [P,3] | rowsum [P] | glv [P,3] | wface [F,3]
+}
+
+// method 0: cot (faces [F,3] packed ids); method 1: uniform (edges [E,2] unique packed edges, F = E).
+int acfm_laplacian_smoothing(const float* verts, const int64_t* conn, const float* vweight, int P, int F,
+                             int method, float* loss, float* state, void* stream) {
+  if (!verts || !conn || !vweight || !loss || !state || P <= 0 || F <= 0 || (method != 0 && method != 1))
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* Wv = state; float* rowsum = state + 3 * (size_t)P; float* glv = state + 4 * (size_t)P;
+  float* wface = state + 7 * (size_t)P;
+  if (hipMemsetAsync(state, 0, sizeof(float) * 4 * (size_t)P, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (method == 0)
+    hipLaunchKernelGGL(k_lap_accum_faces, dim3(nblk(F, 256)), dim3(256), 0, st, verts, conn, P, F, Wv, rowsum, wface);
+  else
+    hipLaunchKernelGGL(k_lap_accum_edges, dim3(nblk(F, 256)), dim3(256), 0, st, verts, conn, P, F, Wv, rowsum);
+  hipLaunchKernelGGL(k_lap_vertex, dim3(nblk(P, MTPB)), dim3(MTPB), 0, st, verts, (const float*)Wv,
+                     (const float*)rowsum, vweight, P, glv, loss);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_laplacian_smoothing_backward(const int64_t* conn, const float* state, const float* grad_loss, int P, int F,
+                                      int method, float* grad_verts, void* stream) {
+  if (!conn || !state || !grad_loss || !grad_verts || P <= 0 || F <= 0 || (method != 0 && method != 1))
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const float* rowsum = state + 3 * (size_t)P; const float* glv = state + 4 * (size_t)P;
+  const float* wface = state + 7 * (size_t)P;
+  hipLaunchKernelGGL(k_lap_bwd_init, dim3(nblk(3L * P, 256)), dim3(256), 0, st, glv, grad_loss, 3 * P, grad_verts);
+  if (method == 0)
+    hipLaunchKernelGGL(k_lap_bwd_faces, dim3(nblk(F, 256)), dim3(256), 0, st, conn, wface, rowsum, glv, grad_loss,
+                       P, F, grad_verts);
+  else
+    hipLaunchKernelGGL(k_lap_bwd_edges, dim3(nblk(F, 256)), dim3(256), 0, st, conn, rowsum, glv, grad_loss, P, F,
+                       grad_verts);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_edge_rigidity(const float* verts, const int64_t* edges, const float* verts_t, const int64_t* edges_t,
+                       int E, float* loss, void* stream) {
+  if (!verts || !edges || !verts_t || !edges_t || !loss || E <= 0) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return ACFM_E_LAUNCH;
+  hipLaunchKernelGGL(k_rigid, dim3(nblk(E, MTPB)), dim3(MTPB), 0, st, verts, edges, verts_t, edges_t, E, loss);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_edge_rigidity_backward(const float* verts, const int64_t* edges, const float* verts_t,
+                                const int64_t* edges_t, int E, int P, int Pt, const float* grad_loss, float* grad_verts,
+                                float* grad_verts_t, void* stream) {
+  if (!verts || !edges || !verts_t || !edges_t || !grad_loss || E <= 0 || P <= 0 || Pt <= 0) return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (grad_verts && hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)P, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (grad_verts_t && hipMemsetAsync(grad_verts_t, 0, sizeof(float) * 3 * (size_t)Pt, st) != hipSuccess) return ACFM_E_LAUNCH;
+  hipLaunchKernelGGL(k_rigid_bwd, dim3(nblk(E, 256)), dim3(256), 0, st, verts, edges, verts_t, edges_t, E, grad_loss,
+                     grad_verts, grad_verts_t);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+}  // extern "C"

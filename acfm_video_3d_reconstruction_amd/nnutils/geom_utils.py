@@ -91,8 +91,12 @@ def mesh_laplacian(meshes, method="uniform"):
         if method == "uniform":
             L = meshes.laplacian_packed().to_dense()
         elif method in ["cot"]:
-            W, _ = laplacian_cot(meshes)
-            L = W - torch.diag(W.sum(dim=1))
+            verts = meshes.verts_packed()
+            if verts.is_cuda:
+                L = ops.cot_laplacian(verts, meshes.faces_packed())   # one fused kernel
+            else:
+                W, _ = laplacian_cot(meshes)
+                L = W - torch.diag(W.sum(dim=1))
         else:
             raise ValueError("method should be one of {uniform, cot}")
     return L

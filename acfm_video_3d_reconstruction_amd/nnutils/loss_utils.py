@@ -113,6 +113,10 @@ def texture_dt_loss(texture_flow, dist_transf, vis_rend=None, cams=None, verts=N
 def locally_rigid_fn(meshes, mesh_template):
     """loss_utils.py:150-164."""
     N = len(meshes)
+    vp = meshes.verts_packed()
+    if vp.is_cuda:
+        return ops.edge_rigidity_sum(vp, meshes.edges_packed(), mesh_template.verts_packed(),
+                                     mesh_template.edges_packed()) / N
     v0, v1 = _edge_lengths(meshes)
     t0, t1 = _edge_lengths(mesh_template)
     loss = ((v0 - v1).norm(dim=1, p=2) - (t0 - t1).norm(dim=1, p=2)) ** 2

@@ -385,3 +385,92 @@ class _BdsLoss(torch.autograd.Function):
 def bds_loss_per_mesh(verts_xy, bds, vis):
     """[N,V,2] x [N,P,3] x uint8 [N,V] -> [N] (sum over boundary points)."""
     return _BdsLoss.apply(verts_xy, bds, vis)
+
+
+# ------------------------------------------------------------------------------ mesh priors
+def cot_laplacian(verts, faces):
+    """Dense cot Laplacian L [V,V] of one mesh (verts [V,3], faces [F,3]); constant (no grad)."""
+    _lib.require_gpu(verts, faces)
+    v = _f32c(verts)
+    f = faces.detach().to(torch.int64).contiguous()
+    V, F = v.shape[0], f.shape[0]
+    L = torch.empty((V, V), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.lib().acfm_cot_laplacian(_lib.ptr(v), _lib.ptr(f), V, F, _lib.ptr(L),
+                                                 _lib.cur_stream(v.device)), "acfm_cot_laplacian")
+    return L
+
+
+class _LaplacianSmoothing(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts_packed, conn, vweight, method):
+        _lib.require_gpu(verts_packed, conn, vweight)
+        v, w = _f32c(verts_packed), _f32c(vweight)
+        c = conn.detach().to(torch.int64).contiguous()
+        P, F = v.shape[0], c.shape[0]
+        n = _lib.lib().acfm_laplacian_smoothing_state_floats(P, F)
+        state = torch.empty(n, dtype=torch.float32, device=v.device)
+        loss = torch.empty((), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_laplacian_smoothing(_lib.ptr(v), _lib.ptr(c), _lib.ptr(w), P, F,
+                                                           int(method), _lib.ptr(loss), _lib.ptr(state),
+                                                           _lib.cur_stream(v.device)),
+                       "acfm_laplacian_smoothing")
+        ctx.save_for_backward(c, state)
+        ctx.cfg = (P, F, int(method))
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        c, state = ctx.saved_tensors
+        P, F, method = ctx.cfg
+        g = _f32c(go).reshape(1)
+        gv = torch.empty((P, 3), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_laplacian_smoothing_backward(_lib.ptr(c), _lib.ptr(state), _lib.ptr(g),
+                                                                    P, F, method, _lib.ptr(gv),
+                                                                    _lib.cur_stream(g.device)),
+                       "acfm_laplacian_smoothing_backward")
+        return gv, None, None, None
+
+
+def laplacian_smoothing_sum(verts_packed, conn, vweight, method):
+    """sum_v vweight[v] * |L v|_v on packed meshes; method 0 = cot (conn = faces), 1 = uniform
+    (conn = unique edges)."""
+    return _LaplacianSmoothing.apply(verts_packed, conn, vweight, method)
+
+
+class _EdgeRigidity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, edges, verts_t, edges_t):
+        _lib.require_gpu(verts, edges, verts_t, edges_t)
+        v, vt = _f32c(verts), _f32c(verts_t)
+        e = edges.detach().to(torch.int64).contiguous()
+        et = edges_t.detach().to(torch.int64).contiguous()
+        if e.shape != et.shape:
+            raise ValueError("meshes and template must have the same number of edges")
+        loss = torch.empty((), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_edge_rigidity(_lib.ptr(v), _lib.ptr(e), _lib.ptr(vt), _lib.ptr(et),
+                                                     e.shape[0], _lib.ptr(loss), _lib.cur_stream(v.device)),
+                       "acfm_edge_rigidity")
+        ctx.save_for_backward(v, e, vt, et)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        v, e, vt, et = ctx.saved_tensors
+        g = _f32c(go).reshape(1)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gvt = torch.empty_like(vt) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_edge_rigidity_backward(
+                _lib.ptr(v), _lib.ptr(e), _lib.ptr(vt), _lib.ptr(et), e.shape[0], v.shape[0], vt.shape[0],
+                _lib.ptr(g), _lib.ptr(gv), _lib.ptr(gvt), _lib.cur_stream(g.device)),
+                "acfm_edge_rigidity_backward")
+        return gv, None, gvt, None
+
+
+def edge_rigidity_sum(verts_packed, edges, verts_t_packed, edges_t):
+    """sum_e (|v[e0]-v[e1]| - |vt[et0]-vt[et1]|)^2 on packed meshes."""
+    return _EdgeRigidity.apply(verts_packed, edges, verts_t_packed, edges_t)

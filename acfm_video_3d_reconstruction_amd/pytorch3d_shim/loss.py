@@ -25,6 +25,10 @@ def mesh_laplacian_smoothing(meshes, method: str = "uniform"):
     faces = meshes.faces_packed()
     weights = 1.0 / meshes.num_verts_per_mesh().gather(0, meshes.verts_packed_to_mesh_idx()).float()
     V = verts.shape[0]
+    if verts.is_cuda and method in ("cot", "uniform"):
+        from .. import ops  # fused gfx950 kernels (csrc/acfm_mesh.hip); torch ops below = host tensors
+        conn = faces if method == "cot" else meshes.edges_packed()
+        return ops.laplacian_smoothing_sum(verts, conn, weights, 0 if method == "cot" else 1) / N
     if method == "uniform":
         L = meshes.laplacian_packed()
         loss = torch.sparse.mm(L, verts)

@@ -4,6 +4,10 @@ through verts_packed / faces_packed / edges_packed / verts_padded / num_verts_pe
 isempty / device / len()."""
 import torch
 
+# edges_packed of a batch is a sort + unique over 3*N*F pairs; the reference rebuilds Meshes every
+# step from the same faces tensor, so the result is memoised on (storage, shape, version).
+_EDGE_CACHE = {}
+
 
 class Meshes:
     def __init__(self, verts=None, faces=None, textures=None):
@@ -97,12 +101,24 @@ class Meshes:
         """Unique (min, max) vertex pairs of all packed faces in lexicographic order
         (SURVEY App-A.9)."""
         if "edges_packed" not in self._cache:
-            f = self.faces_packed()
-            e = torch.cat([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)
-            e = torch.sort(e, dim=1)[0]
-            V = int(self.num_verts_per_mesh().sum().item())
-            key = torch.unique(e[:, 0] * V + e[:, 1], sorted=True)
-            self._cache["edges_packed"] = torch.stack([key // V, key % V], 1)
+            ck = None
+            if self._faces_padded is not None and self._equal_sized():
+                fp_ = self._faces_padded
+                ck = (fp_.data_ptr(), tuple(fp_.shape), fp_._version, str(fp_.device),
+                      self._verts_list[0].shape[0])
+            if ck is not None and ck in _EDGE_CACHE:
+                self._cache["edges_packed"] = _EDGE_CACHE[ck]
+            else:
+                f = self.faces_packed()
+                e = torch.cat([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)
+                e = torch.sort(e, dim=1)[0]
+                V = int(self.num_verts_per_mesh().sum().item())
+                h = torch.unique(e[:, 0] * V + e[:, 1], sorted=True)
+                self._cache["edges_packed"] = torch.stack([h // V, h % V], 1)
+                if ck is not None:
+                    if len(_EDGE_CACHE) > 16:
+                        _EDGE_CACHE.clear()
+                    _EDGE_CACHE[ck] = self._cache["edges_packed"]
         return self._cache["edges_packed"]
 
     def laplacian_packed(self):

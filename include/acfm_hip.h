@@ -198,6 +198,30 @@ int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_
                            const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
                            void* stream);
 
+/* ---- mesh priors -------------------------------------------------------------------------
+ * Packed meshes: verts [P,3] f32, faces [F,3] / edges [E,2] i64 with packed vertex ids.
+ * acfm_cot_laplacian: geom_utils.mesh_laplacian(mesh, 'cot') (multiframe/nnutils/geom_utils.py:
+ *   158-324) for ONE mesh: dense L [V,V] = W - diag(rowsum W), W_ij = (cot a_ij + cot b_ij)/4. */
+int acfm_cot_laplacian(const float* verts, const int64_t* faces, int V, int F, float* L, void* stream);
+/* acfm_laplacian_smoothing: pytorch3d.loss.mesh_laplacian_smoothing (multiframe/main.py:699-704):
+ *   method 0 'cot' (conn = faces [F,3]): loss = sum_v vweight[v] * |(W v)_v / rowsum_v - v_v|;
+ *   method 1 'uniform' (conn = unique edges [F,2]): W_ij = 1 on edges.
+ *   vweight [P] = 1 / (verts of the vertex's mesh); the caller divides the sum by the mesh count.
+ *   loss: 1 float (device); state: acfm_laplacian_smoothing_state_floats(P, F) floats kept for
+ *   the backward, which takes the upstream gradient as a DEVICE scalar. */
+size_t acfm_laplacian_smoothing_state_floats(int P, int F);
+int acfm_laplacian_smoothing(const float* verts, const int64_t* conn, const float* vweight, int P, int F,
+                             int method, float* loss, float* state, void* stream);
+int acfm_laplacian_smoothing_backward(const int64_t* conn, const float* state, const float* grad_loss, int P,
+                                      int F, int method, float* grad_verts, void* stream);
+/* acfm_edge_rigidity: loss_utils.locally_rigid_fn (multiframe/nnutils/loss_utils.py:150-164):
+ *   loss = sum_e (|v[e0]-v[e1]| - |vt[et0]-vt[et1]|)^2 (the caller divides by the mesh count). */
+int acfm_edge_rigidity(const float* verts, const int64_t* edges, const float* verts_t, const int64_t* edges_t,
+                       int E, float* loss, void* stream);
+int acfm_edge_rigidity_backward(const float* verts, const int64_t* edges, const float* verts_t,
+                                const int64_t* edges_t, int E, int P, int Pt, const float* grad_loss,
+                                float* grad_verts, float* grad_verts_t, void* stream);
+
 /* ---- on-device input preparation ----------------------------------------
  * replaces the per-batch CPU work of ShapeTrainer.set_input (multiframe/main.py:365-377) and
  * its device->host->device round trip of the masks.
