@@ -1,0 +1,182 @@
+"""The hot part of ACFM's multiframe training step on the MI355X ops.
+
+`MultiframeStep.warmup` / `.forward` replay the call sequence of `ShapeTrainer.warmup`
+(multiframe/main.py:438-520) and `ShapeTrainer.forward` (:523-765) for everything that sits
+between the network heads and the loss scalar: per-frame camera / probability / deformation
+embeddings with G hypotheses (mesh_net.py:404-451), camera decode + mirror + affine transforms,
+the deformation solve, silhouette / texture renders, silhouette + boundary + optical-flow +
+keypoint losses, the hypothesis softmax weighting and the shape priors.  The learned networks
+(ResNet encoder, texture and camera heads, mesh_net.py) are out of scope: their outputs
+(`delta_v_res`, `textures`) are inputs here.
+
+Tensors follow the reference's shapes: B clips of T frames, N = B*T, G hypotheses, G*N meshes."""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import harness
+from .deform import DeformSolver
+from .nnutils import loss_utils
+from .nnutils.nmr import NeuralRenderer, OF_NeuralRenderer
+from .pytorch3d_shim.loss import mesh_laplacian_smoothing
+from .pytorch3d_shim.structures import Meshes
+
+# defaults of the reference's flags (multiframe/main.py:55-89)
+DEFAULTS = dict(num_frames=2, num_guesses=8, num_lbs=15, kp_loss_wt=0., of_loss_wt=1., mask_loss_wt=1.,
+                rigid_wt=0.5, deform_reg_wt=1., handle_deform_reg_wt=0., boundaries_reg_wt=1., edt_reg_wt=0.1,
+                bdt_reg_wt=2., triangle_reg_wt=0.1, tex_loss_wt=.5, scale_lr_decay=0.05, optimize_deform=False,
+                optimize_deform_lr=100., drop_hypothesis=False, texture=False)
+
+
+def _y_rotation_quats(num_guesses):
+    """mesh_net.py:424-434: hypothesis g starts as a rotation of 360*g/(G-1) degrees about +y."""
+    ang = torch.linspace(0, 360, num_guesses) * math.pi / 180.0
+    return torch.stack([torch.cos(ang / 2), torch.zeros_like(ang), torch.sin(ang / 2), torch.zeros_like(ang)], 1)
+
+
+class MultiframeStep(nn.Module):
+    def __init__(self, mean_v, faces, lbs_logits, num_training_frames, img_size=256, vert2kp=None, **opts):
+        super().__init__()
+        o = dict(DEFAULTS)
+        o.update(opts)
+        self.opts = SimpleNamespace(**o)
+        G = self.opts.num_guesses
+        q0 = _y_rotation_quats(G)
+        self.cameras = nn.ModuleList()
+        for g in range(G):                                       # mesh_net.py:436-444
+            emb = nn.Embedding(num_training_frames, 7)
+            with torch.no_grad():
+                emb.weight[:, 0] = 0
+                emb.weight[:, 1:3] = (torch.rand(2) - 0.5) * 0.1
+                emb.weight[:, 3:] = q0[g] + 0.1 * torch.rand(4)
+            self.cameras.append(emb)
+        self.prob_embeddings = nn.Embedding(num_training_frames, G)
+        self.prob_embeddings.weight.data.fill_(1)               # mesh_net.py:445-446
+        self.deform_emb = nn.Embedding(num_training_frames, self.opts.num_lbs * 3)
+        self.deform_mirror_emb = nn.Embedding(num_training_frames, self.opts.num_lbs * 3)
+        self.deform_emb.weight.data.zero_()                     # mesh_net.py:448-451
+        self.deform_mirror_emb.weight.data.zero_()
+        self.lbs = nn.Parameter(lbs_logits.detach().clone())    # mesh_net.py:543-544
+        self.register_buffer("faces1", faces.detach().clone().long())
+        self.solver = DeformSolver(mean_v, faces, self.lbs)
+        self.vert2kp = vert2kp
+        self.renderer = NeuralRenderer(img_size)
+        self.tex_renderer = NeuralRenderer(img_size)
+        self.of_renderer = OF_NeuralRenderer(img_size)
+
+    # ------------------------------------------------------------------ cameras (main.py:551-584)
+    def hypothesis_cameras(self, frames_idx, mirror_flag, transforms, detach=False):
+        G = self.opts.num_guesses
+        cams = torch.stack([emb(frames_idx) for emb in self.cameras]).reshape(G, -1, 7)
+        cam_pred = harness.decode_cameras(cams, self.opts.scale_lr_decay).reshape(-1, 7)
+        cam_pred = harness.mirror_cameras(cam_pred, None, mirror_flag.repeat(G)[:, None])
+        cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
+        return cam_pred.detach() if detach else cam_pred
+
+    def _silhouette_terms(self, pred_v, faces, cam, batch, G):
+        o = self.opts
+        mask_pred, pix_to_face = self.renderer(pred_v, faces, cam)
+        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, batch["masks"].repeat(G, 1, 1),
+                                                        batch["edts_barrier"].repeat(G, 1, 1, 1))
+        pred_proj = self.renderer.project_points(pred_v, cam)
+        bdt = loss_utils.bds_loss(pred_proj, batch["boundaries"].repeat(G, 1, 1), faces, pix_to_face,
+                                  reduce=False)
+        sil_cons = o.edt_reg_wt * edt + o.bdt_reg_wt * bdt
+        return mask_pred, l1, sil_cons
+
+    def _flow_term(self, pred_v, cam, batch, G):
+        o = self.opts
+        if not (o.of_loss_wt > 0) or "optical_flows" not in batch:
+            return torch.zeros(1, device=pred_v.device)
+        T = o.num_frames
+        B = batch["masks"].shape[0] // T
+        masks_of = batch["masks"].reshape(B, T, *batch["masks"].shape[1:])
+        flows = (torch.flip(batch["optical_flows"], dims=[1]) * masks_of[..., None]).repeat(G, 1, 1, 1, 1)
+        faces_of = self.faces1[None, None].expand(G * B, T, -1, -1)
+        of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, flows,
+                                                           self.of_renderer, pix_to_face=None, reduce=False)
+        return of_loss.reshape(G, -1).repeat(1, T).reshape(G, -1)    # main.py:684-686
+
+    # ------------------------------------------------------------------ main.py:438-520
+    def warmup(self, batch):
+        """Pose warm-up: render the undeformed mean shape under all G camera hypotheses; only the
+        camera embeddings receive gradients; writes the hypothesis probabilities."""
+        o = self.opts
+        G = o.num_guesses
+        N = batch["masks"].shape[0]
+        cam = self.hypothesis_cameras(batch["frames_idx"], batch["mirror_flag"], batch["transforms"])
+        mean_v = self.solver.mean_v[None].repeat(G * N, 1, 1)
+        faces = self.faces1[None].expand(G * N, -1, -1)
+        _, mask_loss, sil_cons = self._silhouette_terms(mean_v, faces, cam, batch, G)
+        total = o.mask_loss_wt * mask_loss.reshape(G, N) + o.of_loss_wt * self._flow_term(mean_v, cam, batch, G) \
+            + o.boundaries_reg_wt * sil_cons.reshape(G, N)
+        if o.kp_loss_wt > 0 and self.vert2kp is not None:
+            kp_v = torch.matmul(torch.softmax(self.vert2kp, dim=1), mean_v)
+            kp = loss_utils.kp_l2_loss(self.renderer.project_points(kp_v, cam), batch["kps"].repeat(G, 1, 1),
+                                       reduction="none")
+            total = total + o.kp_loss_wt * kp.reshape(G, N)
+        probs = torch.softmax(-total, dim=0).detach()
+        with torch.no_grad():                                    # main.py:517-519
+            self.prob_embeddings.weight[batch["frames_idx"]] = \
+                probs.reshape(G, *batch["frames_idx"].shape).permute(1, 2, 0)
+        return total.mean(), probs
+
+    # ------------------------------------------------------------------ main.py:523-765
+    def forward(self, batch, delta_v_res, textures=None, imgs=None, detach_camera=False, drop_deform=False):
+        """delta_v_res [N,K_h,3]: handle offsets predicted by the (out-of-scope) encoder head.
+        Returns (total_loss, dict of the reference's named terms)."""
+        o = self.opts
+        G, T = o.num_guesses, o.num_frames
+        N = delta_v_res.shape[0]
+        cam = self.hypothesis_cameras(batch["frames_idx"], batch["mirror_flag"], batch["transforms"],
+                                      detach=detach_camera)
+        # deformation (main.py:586-609): delta = 0 when drop_deform, embeddings when optimize_deform
+        if drop_deform:
+            delta = torch.zeros_like(delta_v_res)
+        elif o.optimize_deform:
+            flag = batch["mirror_flag"][:, None, None].float()
+            d0 = self.deform_emb(batch["frames_idx"]).reshape(-1, o.num_lbs, 3)
+            d1 = self.deform_mirror_emb(batch["frames_idx"]).reshape(-1, o.num_lbs, 3)
+            delta = ((1 - flag) * d0 + flag * d1) * o.optimize_deform_lr
+        else:
+            delta = delta_v_res
+        self.solver.refresh()                                    # lbs changed in the last optimiser step
+        pred_v1 = self.solver(delta)                             # [N,V,3]
+        pred_v = pred_v1.repeat(G, 1, 1)
+        faces = self.faces1[None].expand(G * N, -1, -1)
+        terms = {}
+        mask_pred, mask_loss, sil_cons = self._silhouette_terms(pred_v, faces, cam, batch, G)
+        total = o.mask_loss_wt * mask_loss.reshape(G, N)
+        total = total + o.of_loss_wt * self._flow_term(pred_v, cam, batch, G)
+        total = total + o.boundaries_reg_wt * sil_cons.reshape(G, N)
+        if o.kp_loss_wt > 0 and self.vert2kp is not None:
+            kp_v = torch.matmul(torch.softmax(self.vert2kp, dim=1), pred_v)
+            kp = loss_utils.kp_l2_loss(self.renderer.project_points(kp_v, cam), batch["kps"].repeat(G, 1, 1),
+                                       reduction="none")
+            total = total + o.kp_loss_wt * kp.reshape(G, N)
+        if textures is not None and imgs is not None:
+            # texture branch on detached geometry, original + mirrored camera (main.py:627-636, 655-662;
+            # the LPIPS part of the reference's texture loss is out of scope)
+            tex = textures.repeat(G, 1, 1, 1, 1)
+            tex_pred, _, _ = self.tex_renderer(pred_v.detach(), faces, cam, textures=tex)
+            imgs_f, cam_f, _, masks_f = harness.mirror_sample(imgs, cam, mask_pred, batch["masks"])
+            tex_pred_f, _, _ = self.tex_renderer(pred_v.detach(), faces, cam_f, textures=tex)
+            mse = 0.5 * (loss_utils.masked_texture_mse(tex_pred, imgs.repeat(G, 1, 1, 1), batch["masks"].repeat(G, 1, 1))
+                         + loss_utils.masked_texture_mse(tex_pred_f, imgs_f.repeat(G, 1, 1, 1), masks_f.repeat(G, 1, 1)))
+            total = total + o.tex_loss_wt * mse.reshape(G, N)
+            terms["tex_mse"] = mse.mean().detach()
+        # hypothesis weighting (main.py:735-746)
+        weighted, probs, cam_loss = harness.hypothesis_weighting(total)
+        # priors on the deformed shape (main.py:698-714, 748-751)
+        faces_n = self.faces1[None].expand(N * G, -1, -1)
+        mesh_3d = Meshes(verts=pred_v, faces=faces_n)
+        mesh_t = Meshes(verts=self.solver.mean_v[None].repeat(G * N, 1, 1), faces=faces_n)
+        triangle = mesh_laplacian_smoothing(mesh_3d, method="cot")
+        rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
+        handle = loss_utils.deform_l2reg(delta_v_res)
+        loss = weighted + o.rigid_wt * rigid + o.triangle_reg_wt * triangle + o.handle_deform_reg_wt * handle
+        terms.update(mask=mask_loss.mean().detach(), sil_cons=sil_cons.mean().detach(), rigid=rigid.detach(),
+                     triangle=triangle.detach(), camera_loss=cam_loss.detach(), probs=probs)
+        return loss, terms

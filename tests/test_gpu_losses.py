@@ -227,3 +227,58 @@ def test_mesh_priors_hip(meshes):
     rv = torch.from_numpy(g["rigid_v"]).double().requires_grad_(True)
     O.locally_rigid(rv, bv[None].repeat(4, 1, 1).double(), torch.from_numpy(O.edges_packed(meshes["bird_f"]))).backward()
     np.testing.assert_allclose(dv.grad.cpu().numpy(), rv.grad.numpy(), rtol=1e-3, atol=1e-6)
+
+
+def test_multiframe_step_harness(meshes):
+    """ShapeTrainer.warmup / forward (main.py:438-520, 523-765) replayed on the HIP
+    ops with G camera hypotheses, embeddings and stub network outputs."""
+    from acfm_video_3d_reconstruction_amd import image_utils as IU
+    from acfm_video_3d_reconstruction_amd.multiframe_step import MultiframeStep
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
+    d = _d()
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    B, T, G, H, Kh = 2, 2, 3, 64, 15
+    N = B * T
+    step = MultiframeStep(torch.tensor(v, device=d), torch.tensor(f, device=d),
+                          torch.tensor(fps_lbs_logits(v, Kh), device=d), num_training_frames=10, img_size=H,
+                          num_guesses=G, num_lbs=Kh, scale_lr_decay=1.0).to(d)
+    gt_cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
+    with torch.no_grad():
+        gt_mask, _ = step.renderer(step.solver.mean_v[None].repeat(N, 1, 1), step.faces1[None].expand(N, -1, -1), gt_cams)
+        gt_mask = (gt_mask > 0.5).float()
+    batch = dict(masks=gt_mask, edts_barrier=IU.compute_dt(gt_mask, norm=False)[:, None].contiguous(),
+                 boundaries=IU.compute_boundaries(gt_mask), frames_idx=torch.tensor([[0, 1], [4, 5]], device=d),
+                 mirror_flag=torch.tensor([0, 0, 1, 1], device=d),
+                 transforms=torch.tensor([[1., 0, 0, 0]] * N, device=d),
+                 optical_flows=torch.randn(B, T, H, H, 2, device=d))
+    # warm-up: gradients reach the camera embeddings only, probabilities are written back
+    loss, probs = step.warmup(batch)
+    loss.backward()
+    assert all(e.weight.grad is not None and e.weight.grad.abs().sum() > 0 for e in step.cameras)
+    assert step.lbs.grad is None
+    assert probs.shape == (G, N) and torch.allclose(probs.sum(0), torch.ones(N, device=d), atol=1e-5)
+    pw = step.prob_embeddings.weight[batch["frames_idx"]]
+    assert torch.allclose(pw.sum(-1), torch.ones(B, T, device=d), atol=1e-5)
+    opt = torch.optim.Adam([p for e in step.cameras for p in e.parameters()], lr=1e-2)
+    first = None
+    for _ in range(8):
+        opt.zero_grad()
+        loss, _ = step.warmup(batch)
+        loss.backward()
+        opt.step()
+        first = first if first is not None else loss.item()
+    assert loss.item() < first
+    # full forward: textures + mirrored texture render, priors, hypothesis weighting
+    step.zero_grad()
+    delta = (0.01 * torch.randn(N, Kh, 3, device=d)).requires_grad_(True)
+    tex = torch.rand(N, f.shape[0], 4, 4, 3, device=d, requires_grad=True)
+    imgs = torch.rand(N, 3, H, H, device=d)
+    total, terms = step(batch, delta, textures=tex, imgs=imgs)
+    total.backward()
+    assert torch.isfinite(total) and all(torch.isfinite(t).all() for t in (delta.grad, tex.grad, step.lbs.grad))
+    assert delta.grad.abs().sum() > 0 and tex.grad.abs().sum() > 0 and step.lbs.grad.abs().sum() > 0
+    assert set(["mask", "sil_cons", "rigid", "triangle", "camera_loss", "probs", "tex_mse"]) <= set(terms)
+    total2, _ = step(batch, delta, drop_deform=True, detach_camera=True)     # train_utils.py:252's call
+    assert torch.isfinite(total2)
