@@ -214,6 +214,32 @@ def main():
              of_p2f=of_p2f.numpy(), of_loss=loss.numpy(), of_pred=of_pred.numpy(),
              of_vis=vis.numpy())
     np.savez_compressed(os.path.join(OUT, "losses.npz"), **g)
+
+    # ---- (5) exported-but-never-called surface
+    g = {}
+    Fn, Tt, Hh = 12, 3, 16
+    tflow = torch.rand(2, Fn, Tt, Tt, 2) * 2 - 1
+    images = torch.rand(2, 3, Hh, Hh)
+    dtf = torch.rand(2, 1, Hh, Hh)
+    vflow = torch.rand(2, 20, 2) * 2 - 1
+    g.update(tflow=tflow.numpy(), images=images.numpy(), dtf=dtf.numpy(), vflow=vflow.numpy())
+    g["sample_textures"] = geom_utils.sample_textures(tflow, images).numpy()
+    g["sample_textures_v"] = geom_utils.sample_textures_v(vflow, images).numpy()
+    g["texture_dt_loss"] = loss_utils.texture_dt_loss(tflow, dtf).numpy()
+    g["texture_dt_loss_v"] = loss_utils.texture_dt_loss_v(vflow, dtf, reduce=False).numpy()
+    g["texture_dt_loss_v_r"] = loss_utils.texture_dt_loss_v(vflow, dtf).numpy()
+    g["mask_dt_loss"] = loss_utils.mask_dt_loss(vflow, dtf).numpy()
+    tv = torch.rand(2, 9, 3)
+    e2v = torch.randint(0, 9, (2, 7, 4))
+    g.update(tri_v=tv.numpy(), tri_e2v=e2v.numpy())
+    g["triangle_loss"] = loss_utils.triangle_loss(tv, e2v).numpy()
+    pa = torch.softmax(torch.randn(5, 30), 1)
+    g["entropy_in"] = pa.numpy()
+    g["entropy_loss"] = loss_utils.entropy_loss(pa).numpy()
+    g["template_edge_loss"] = loss_utils.template_edge_loss(DuckMesh(vd.reshape(-1, 3), None, ep, N),
+                                                            DuckMesh(vt.reshape(-1, 3), None, ep, N)).numpy()
+    g["texture_loss"] = loss_utils.texture_loss(images, images.flip(0), dtf[:, 0], dtf[:, 0].flip(0)).numpy()
+    np.savez_compressed(os.path.join(OUT, "legacy.npz"), **g)
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -138,3 +138,27 @@ def test_product_laplacian_rigid_and_solve_vs_reference_golden(meshes):
         np.testing.assert_allclose(mp.grad.numpy(), w.sum(0).numpy(), rtol=1e-5, atol=1e-6)
         sc = np.abs(lr.grad.numpy()).max()
         np.testing.assert_allclose(lg.grad.numpy(), lr.grad.numpy(), rtol=1e-2, atol=1e-3 * sc)
+
+
+def test_exported_never_called_surface_vs_reference(meshes):
+    """thin wrappers the reference exports but never calls -- same outputs."""
+    g, gl = load_golden("legacy"), load_golden("losses")
+    tflow, images, dtf, vflow = T(g["tflow"]), T(g["images"]), T(g["dtf"]), T(g["vflow"])
+    tol = dict(rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(geom_utils.sample_textures(tflow, images).numpy(), g["sample_textures"], **tol)
+    np.testing.assert_allclose(geom_utils.sample_textures_v(vflow, images).numpy(), g["sample_textures_v"], **tol)
+    np.testing.assert_allclose(loss_utils.texture_dt_loss(tflow, dtf).numpy(), g["texture_dt_loss"], **tol)
+    np.testing.assert_allclose(loss_utils.texture_dt_loss_v(vflow, dtf, reduce=False).numpy(), g["texture_dt_loss_v"], **tol)
+    np.testing.assert_allclose(loss_utils.texture_dt_loss_v(vflow, dtf).numpy(), g["texture_dt_loss_v_r"], **tol)
+    np.testing.assert_allclose(loss_utils.mask_dt_loss(vflow, dtf).numpy(), g["mask_dt_loss"], **tol)
+    np.testing.assert_allclose(loss_utils.triangle_loss(T(g["tri_v"]), T(g["tri_e2v"])).numpy(), g["triangle_loss"], **tol)
+    np.testing.assert_allclose(loss_utils.entropy_loss(T(g["entropy_in"])).numpy(), g["entropy_loss"], **tol)
+    np.testing.assert_allclose(loss_utils.texture_loss(images, images.flip(0), dtf[:, 0], dtf[:, 0].flip(0)).numpy(),
+                               g["texture_loss"], **tol)
+    v, f = T(meshes["bird_v"]), T(meshes["bird_f"])
+    faces4 = f[None].repeat(4, 1, 1)
+    te = loss_utils.template_edge_loss(Meshes(verts=T(gl["rigid_v"]), faces=faces4),
+                                       Meshes(verts=v[None].repeat(4, 1, 1), faces=faces4))
+    np.testing.assert_allclose(te.item(), g["template_edge_loss"], rtol=1e-5)
+    loss, head = loss_utils.TexCycle()(tflow, torch.rand(2, 12, 2), torch.randint(-1, 12, (2, 8, 8)))
+    assert loss.dim() == 0 and head.shape == (10, 2)
