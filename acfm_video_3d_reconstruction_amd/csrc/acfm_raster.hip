@@ -901,7 +901,7 @@ const char* acfm_prof_name(int id) {
       "k_setup", "k_raster_fwd<K,soft>", "k_sil_bwd", "k_project_bwd", "k_raster_fwd<1,tex>",
       "k_raster_fwd<1,hard>", "k_tex_bwd", "k_mask_losses", "k_mask_losses_bwd", "k_visible",
       "k_bds_loss", "k_bds_loss_bwd", "k_project", "k_tex_mse", "k_tex_mse_bwd", "k_deform_apply",
-      "k_deform_bwd", "", "", "", "", "", "", ""};
+      "k_deform_bwd", "deform_solve", "deform_solve_bwd", "", "", "", "", ""};
   return (id >= 0 && id < ACFM_PROF_NKERNELS) ? names[id] : "";
 }
 

@@ -1,0 +1,485 @@
+// Template deformation solve: P = (L^T L + A^T A)^-1 A^T and its backward, fp64 on the matrix
+// cores.
+//
+// The reference builds M = L^T L + A^T A (A = softmax(lbs, dim 0)^T, L = cotangent Laplacian of
+// the current mean shape, no grad) for every frame and calls torch.cholesky + cholesky_solve
+// (multiframe/main.py:586-609).  Both the mean shape and lbs are learned, so M changes every
+// optimiser step: one V x V SPD factorisation per step is part of the training hot path.  This
+// file does it once per step for all frames (deform.py) as a right-looking blocked Cholesky
+// with 32 x 32 tiles, fp64 throughout (v_mfma_f64_16x16x4_f64):
+//
+//   k_solve_softmax   A = softmax over vertices of each handle's logits (fp64), one WG per handle
+//   k_solve_gram_rows W = L^T L + A^T A, one WG per row; only the non-zeros of L's column are
+//                     visited (the cotangent Laplacian has ~7 per column), fixed summation order
+//   k_chol_step(k)    one launch per tile column k:  L_ik = W_ik L_kk^-T for the tiles below the
+//                     diagonal (recomputed inside every consumer instead of a second launch),
+//                     W_ij -= L_ik L_jk^T on the trailing tiles, and the WG that owns the next
+//                     diagonal tile factorises it (one wave, registers only) and inverts the factor.
+//                     Two more groups of tile rows ride along: the right-hand sides A (so
+//                     Y^T = A L^-T is free) and an identity (so R = L^-T is free): both only add
+//                     independent tiles to launches whose critical path is the diagonal tile.
+//   k_apply_R         P = R Y: with R explicit the substitutions are tile GEMMs, one WG per
+//                     32 vertices, no serial chain
+// backward (dP -> dlbs):  Q = M^-1 dP = R (R^T dP)  (k_apply_R twice),
+//   dA = Q^T - (A Q) P^T - (A P) Q^T,   dlbs = softmax backward per handle     (k_solve_bwd_lbs)
+//
+// Storage: (2 nblk + 1) x nblk tiles, row-major, ld = n_pad = 32 nblk; tile rows [0, nblk) the
+// matrix, tile row nblk the right-hand sides (row h = handle h), tile rows (nblk, 2 nblk] the
+// identity / R.  Indices in [n, n_pad) are padded with the identity.
+#include "acfm_common.h"
+
+#pragma clang fp contract(fast)  // fp64 solve: fused multiply-adds are welcome here
+
+namespace acfm {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NB = 32;        // tile edge
+constexpr int LDT = NB + 2;   // padded LDS row stride (doubles); even: rows stay 16-byte aligned
+constexpr int KHP = 32;       // max handles = one tile row
+
+struct SolveWs {
+  double* W;     // [(2 nblk+1)*32, n_pad] working matrix (trailing updates in place)
+  double* Lf;    // same shape: the factor L; tile row nblk = Y^T = A L^-T; tile rows above = R = L^-T
+  double* Linv;  // [nblk, 32, 32] inverses of the diagonal factor tiles
+  double* A64;   // [32, n_pad] handle weights
+  double* X;     // [n_pad, 32] P in fp64
+  double* Z;     // [n_pad, 32] backward: R^T dP
+  double* Q;     // [n_pad, 32] backward: M^-1 dP
+  int* info;     // 0, or 1 + index of the first non-positive pivot
+  int n, n_pad, nblk, ld;
+  size_t bytes;
+};
+
+static inline SolveWs carve_solve(void* base, int V) {
+  SolveWs s;
+  s.n = V;
+  s.nblk = (V + NB - 1) / NB;
+  s.n_pad = s.nblk * NB;
+  s.ld = s.n_pad;
+  char* p = (char*)base;
+  size_t o = 0;
+  const size_t mat = sizeof(double) * (size_t)(2 * s.n_pad + NB) * s.ld;
+  s.W = (double*)(p + o);    o += align256(mat);
+  s.Lf = (double*)(p + o);   o += align256(mat);
+  s.Linv = (double*)(p + o); o += align256(sizeof(double) * (size_t)s.nblk * NB * NB);
+  s.A64 = (double*)(p + o);  o += align256(sizeof(double) * (size_t)KHP * s.n_pad);
+  s.X = (double*)(p + o);    o += align256(sizeof(double) * (size_t)s.n_pad * KHP);
+  s.Z = (double*)(p + o);    o += align256(sizeof(double) * (size_t)s.n_pad * KHP);
+  s.Q = (double*)(p + o);    o += align256(sizeof(double) * (size_t)s.n_pad * KHP);
+  s.info = (int*)(p + o);    o += 256;
+  s.bytes = o;
+  return s;
+}
+
+__device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// v_mfma_f64_16x16x4_f64 result element e of lane l sits at row (l>>4) + 4e, column l&15
+__device__ __forceinline__ int acc_row(int lane, int e) { return (lane >> 4) + 4 * e; }
+
+__device__ __forceinline__ double bcast_lane(double x, int src) {  // src: compile-time lane
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+
+template <class OP>
+__device__ __forceinline__ double block_reduce(double v, double* scratch /*[256]*/, OP op) {
+  const int t = threadIdx.x;
+  scratch[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) scratch[t] = op(scratch[t], scratch[t + s]);
+    __syncthreads();
+  }
+  const double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+// C (32x32, quadrant of this wave) += sum_p Aop(r, p) * Bop(p, c);  fa(r, p), fb(p, c) with
+// r, c in [0,16) relative to the wave's quadrant
+template <class FA, class FB>
+__device__ __forceinline__ f64x4 tile_mma(int lane, f64x4 acc, FA&& fa, FB&& fb) {
+  const int x = lane & 15, y = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < NB; k0 += 4) acc = mfma64(fa(x, k0 + y), fb(k0 + y, x), acc);
+  return acc;
+}
+
+// One wave factorises the SPD tile in sC (lower part read) in place and inverts the factor.
+// On return sC = L (upper part zero), sX = L^-1.  Lanes 0-31: lane r builds row r of L
+// (left-looking: L_rj = (C_rj - sum_{p<j} L_rp L_jp) / L_jj); lanes 32-63: lane 32+c builds
+// column c of L^-1 by forward substitution (x_j = (delta_jc - sum_{p<j} L_jp x_p) / L_jj).  Both
+// recurrences are  u_j = (init - sum_{p<j} u_p L_jp) / L_jj  with the same wave-uniform L_jp, so
+// one instruction stream serves both halves.  Row j of L is read back from LDS (two entries per
+// ds_read_b128, same address in every lane) except its newest entry L_j,j-1, which comes straight
+// from lane j's register so that no LDS round trip sits on the pivot chain.  1/sqrt by v_rsq_f64 +
+// two Newton steps (no IEEE divide / sqrt sequences on the serial chain).
+__device__ __forceinline__ void potrf32_inv(double (*sC)[LDT], double (*sX)[LDT], int lane, int base_index, int* info) {
+  const int r = lane & 31;
+  const bool low = lane < 32;
+  double u[NB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double s0 = low ? sC[r][j] : (r == j ? 1.0 : 0.0), s1 = 0.0;
+    int p = 0;
+#pragma unroll
+    for (; p + 2 <= j - 1; p += 2) {
+      const double2 l = *reinterpret_cast<const double2*>(&sC[j][p]);
+      s0 -= u[p] * l.x;
+      s1 -= u[p + 1] * l.y;
+    }
+    if (p < j - 1) s1 -= u[p] * sC[j][p];
+    if (j > 0) s0 -= u[j - 1] * bcast_lane(u[j - 1], j);
+    const double sum = s0 + s1;
+    const double piv = bcast_lane(sum, j);
+    bad = bad || !(piv > 0.0);
+    double y = __builtin_amdgcn_rsq(piv);
+    const double hp = 0.5 * piv;
+    y = y + y * (0.5 - hp * y * y);
+    y = y + y * (0.5 - hp * y * y);
+    double v = sum * y;
+    v = (low && r == j) ? piv * y : v;
+    v = (low && r < j) ? 0.0 : v;
+    u[j] = v;
+    if (low) sC[r][j] = v;
+  }
+  if (bad && lane == 0) atomicMax(info, base_index + 1);
+  if (!low) {
+#pragma unroll
+    for (int p = 0; p < NB; ++p) sX[p][r] = u[p];
+  }
+}
+
+// ---- A = softmax(lbs[:, h]) over the vertices, fp64; grid = 32 (rows >= Kh are zero) ----------
+__global__ __launch_bounds__(256) void k_solve_softmax(const float* __restrict__ lbs, SolveWs s, int Kh) {
+  __shared__ double scratch[256];
+  const int h = blockIdx.x, t = threadIdx.x;
+  double* rowW = s.W + (size_t)(s.n_pad + h) * s.ld;
+  double* rowA = s.A64 + (size_t)h * s.n_pad;
+  if (h == 0 && t == 0) *s.info = 0;
+  // identity under the right-hand sides (the region was zeroed by the host): R = L^-T rides along
+  for (int v = h * 256 + t; v < s.n_pad; v += KHP * 256) s.W[(size_t)(s.n_pad + NB + v) * s.ld + v] = 1.0;
+  if (h >= Kh) {
+    for (int v = t; v < s.n_pad; v += 256) rowW[v] = rowA[v] = 0.0;
+    return;
+  }
+  double m = -1e300;
+  for (int v = t; v < s.n; v += 256) m = fmax(m, (double)lbs[(size_t)v * Kh + h]);
+  m = block_reduce(m, scratch, [](double a, double b) { return fmax(a, b); });
+  double sum = 0.0;
+  for (int v = t; v < s.n; v += 256) sum += exp((double)lbs[(size_t)v * Kh + h] - m);
+  sum = block_reduce(sum, scratch, [](double a, double b) { return a + b; });
+  for (int v = t; v < s.n_pad; v += 256)
+    rowW[v] = rowA[v] = v < s.n ? exp((double)lbs[(size_t)v * Kh + h] - m) / sum : 0.0;
+}
+
+// ---- W = L^T L + A^T A, one WG per row i (all columns written: the matrix is symmetric) ---------
+// W[i][c] = sum_h A[h][i] A[h][c] + sum_r L[r][i] L[r][c]: the WG scans column i of L, keeps the
+// non-zero (r, L[r][i]) in ascending r, and adds those rows of L; each output element is summed
+// by one thread in a fixed order (h ascending, then r ascending).
+constexpr int GRAM_CPT = 4;  // columns per thread and pass
+__global__ __launch_bounds__(256) void k_solve_gram_rows(const float* __restrict__ L, SolveWs s, int Kh) {
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int n = s.n;
+  double* wrow = s.W + (size_t)i * s.ld;
+  if (i >= n) {
+    for (int c = t; c < s.n_pad; c += 256) wrow[c] = (c == i) ? 1.0 : 0.0;
+    return;
+  }
+  __shared__ int s_r[256];
+  __shared__ double s_v[256];
+  __shared__ int s_wcnt[4];
+  for (int cb = 0; cb < s.n_pad; cb += 256 * GRAM_CPT) {
+    double acc[GRAM_CPT];
+    int col[GRAM_CPT];
+#pragma unroll
+    for (int q = 0; q < GRAM_CPT; ++q) {
+      col[q] = cb + t + 256 * q;
+      acc[q] = 0.0;
+      if (col[q] < n)
+        for (int h = 0; h < Kh; ++h)
+          acc[q] += s.A64[(size_t)h * s.n_pad + i] * s.A64[(size_t)h * s.n_pad + col[q]];
+    }
+    for (int r0 = 0; r0 < n; r0 += 256) {
+      const int r = r0 + t;
+      const float val = r < n ? L[(size_t)r * n + i] : 0.f;
+      const bool nz = val != 0.f;
+      const unsigned long long bal = __ballot(nz);
+      if (lane == 0) s_wcnt[w] = __popcll(bal);
+      __syncthreads();
+      int off = __popcll(bal & ((1ull << lane) - 1ull));
+      for (int ww = 0; ww < w; ++ww) off += s_wcnt[ww];
+      const int cnt = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      if (nz) { s_r[off] = r; s_v[off] = (double)val; }
+      __syncthreads();
+      for (int e = 0; e < cnt; ++e) {
+        const float* lrow = L + (size_t)s_r[e] * n;
+        const double lv = s_v[e];
+#pragma unroll
+        for (int q = 0; q < GRAM_CPT; ++q)
+          if (col[q] < n) acc[q] += lv * (double)lrow[col[q]];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < GRAM_CPT; ++q)
+      if (col[q] < s.n_pad) wrow[col[q]] = acc[q];
+  }
+}
+
+// ---- factorise tile (0,0); one WG ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_first(SolveWs s) {
+  __shared__ __attribute__((aligned(16))) double sA[NB][LDT], sB[NB][LDT];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+    sA[rr][cc] = s.W[(size_t)rr * s.ld + cc];
+  }
+  __syncthreads();
+  if (w == 0) potrf32_inv(sA, sB, lane, 0, s.info);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+    s.Lf[(size_t)rr * s.ld + cc] = sA[rr][cc];
+    s.Linv[rr * NB + cc] = sB[rr][cc];
+  }
+}
+
+// ---- one tile column of the factorisation; grid (m+1, nblk+1), m = nblk-1-k --------------------
+// blockIdx.y -> tile row i: y < m the matrix rows k+1+y, y == m the right-hand sides (i = nblk),
+// y > m the identity rows 0..k (i = nblk+1+(y-m-1); rows below k are still zero in column k).
+// blockIdx.x < m -> update of tile (i, j = k+1+x), blockIdx.x == m -> store L_ik.
+__global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
+  const int m = s.nblk - 1 - k;
+  const int y = blockIdx.y;
+  const int i = y < m ? k + 1 + y : s.nblk + (y - m);
+  const bool panel = (int)blockIdx.x == m;
+  const int j = panel ? i : k + 1 + (int)blockIdx.x;
+  if (!panel && j > i) return;
+  __shared__ __attribute__((aligned(16))) double sInv[NB][LDT], sWi[NB][LDT], sWj[NB][LDT], sLi[NB][LDT], sLj[NB][LDT];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int qi = w >> 1, qj = w & 1;
+  const double* inv = s.Linv + (size_t)k * NB * NB;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+    sInv[rr][cc] = inv[rr * NB + cc];
+    sWi[rr][cc] = s.W[(size_t)(NB * i + rr) * s.ld + NB * k + cc];
+    if (!panel && j != i) sWj[rr][cc] = s.W[(size_t)(NB * j + rr) * s.ld + NB * k + cc];
+  }
+  __syncthreads();
+  const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+  const int col = 16 * qj + (lane & 15);
+  // L_ik = W_ik L_kk^-T
+  f64x4 li = tile_mma(lane, zero, [&](int r, int p) { return sWi[16 * qi + r][p]; },
+                      [&](int p, int c) { return sInv[16 * qj + c][p]; });
+  if (panel) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      s.Lf[(size_t)(NB * i + 16 * qi + acc_row(lane, e)) * s.ld + NB * k + col] = li[e];
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sLi[16 * qi + acc_row(lane, e)][col] = li[e];
+  if (j != i) {
+    f64x4 lj = tile_mma(lane, zero, [&](int r, int p) { return sWj[16 * qi + r][p]; },
+                        [&](int p, int c) { return sInv[16 * qj + c][p]; });
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sLj[16 * qi + acc_row(lane, e)][col] = lj[e];
+  }
+  __syncthreads();
+  double(*sR)[LDT] = (j != i) ? sLj : sLi;
+  f64x4 acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    acc[e] = s.W[(size_t)(NB * i + 16 * qi + acc_row(lane, e)) * s.ld + NB * j + col];
+  acc = tile_mma(lane, acc, [&](int r, int p) { return -sLi[16 * qi + r][p]; },
+                 [&](int p, int c) { return sR[16 * qj + c][p]; });
+  const bool next_diag = (i == k + 1) && (j == k + 1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = 16 * qi + acc_row(lane, e);
+    s.W[(size_t)(NB * i + row) * s.ld + NB * j + col] = acc[e];
+    if (next_diag) sWi[row][col] = acc[e];
+  }
+  if (next_diag) {
+    __syncthreads();
+    if (w == 0) potrf32_inv(sWi, sWj, lane, NB * i, s.info);
+    __syncthreads();
+    double* invn = s.Linv + (size_t)i * NB * NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sWi[rr][cc];
+      invn[rr * NB + cc] = sWj[rr][cc];
+    }
+  }
+}
+
+// ---- out = R rhs (TRANS: R^T rhs), R = L^-T upper block-triangular; grid = nblk ------------------
+// WG c produces the 32 vertices of tile row c for all handles.  Right-hand sides and results are
+// [n_pad][32] (vertex-major); RHS 0: rhs^T = Y^T in the factor's right-hand-side tile row,
+// 1: an [n_pad][32] fp64 buffer, 2: an fp32 [V][Kh] tensor (the incoming gradient).
+template <bool TRANS, int RHS>
+__global__ __launch_bounds__(256) void k_apply_R(SolveWs s, const double* __restrict__ rhs64,
+                                                 const float* __restrict__ rhs32, int Kh,
+                                                 double* __restrict__ out, float* __restrict__ out32) {
+  __shared__ double sRed[2][2][4][64];
+  const int c = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int qj = w & 1, par = w >> 1;
+  const int nqi = Kh > 16 ? 2 : 1;
+  const int x = lane & 15, y = lane >> 4;
+  const int n = s.n, ld = s.ld, nblk = s.nblk;
+  const double* R = s.Lf + (size_t)(s.n_pad + NB) * ld;
+  f64x4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  const int pb = (TRANS ? 0 : c) + par, pe = TRANS ? c + 1 : nblk;
+  for (int p = pb; p < pe; p += 2) {
+    double a[2][8], b[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int q = 4 * ks + y;
+      b[ks] = TRANS ? R[(size_t)(NB * p + q) * ld + NB * c + 16 * qj + x]
+                    : R[(size_t)(NB * c + 16 * qj + x) * ld + NB * p + q];
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {
+        if (qi >= nqi) continue;
+        const int h = 16 * qi + x, v = NB * p + q;
+        if (RHS == 0) a[qi][ks] = s.Lf[(size_t)(s.n_pad + h) * ld + v];
+        else if (RHS == 1) a[qi][ks] = rhs64[(size_t)v * KHP + h];
+        else a[qi][ks] = (v < n && h < Kh) ? (double)rhs32[(size_t)v * Kh + h] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi)
+        if (qi < nqi) acc[qi] = mfma64(a[qi][ks], b[ks], acc[qi]);
+  }
+  if (par == 1) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (qi < nqi) sRed[qi][qj][e][lane] = acc[qi][e];
+  }
+  __syncthreads();
+  if (par == 0) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (qi >= nqi) continue;
+        const int h = 16 * qi + acc_row(lane, e), v = NB * c + 16 * qj + x;
+        const double r = acc[qi][e] + sRed[qi][qj][e][lane];
+        out[(size_t)v * KHP + h] = r;
+        if (out32 && v < n && h < Kh) out32[(size_t)v * Kh + h] = (float)r;
+      }
+  }
+}
+
+// ---- dlbs from Q = M^-1 dP; grid = Kh, one handle (one softmax column) per WG -------------------
+__global__ __launch_bounds__(256) void k_solve_bwd_lbs(SolveWs s, int Kh, float* __restrict__ grad_lbs) {
+  __shared__ double scratch[256];
+  __shared__ double sAQ[KHP], sAP[KHP];
+  const int h = blockIdx.x, t = threadIdx.x;
+  const double* a_row = s.A64 + (size_t)h * s.n_pad;
+  {  // (A Q)[h][h'], (A P)[h][h']: 8 partial sums per output
+    const int hp = t & 31, part = t >> 5;
+    double aq = 0.0, ap = 0.0;
+    for (int v = part; v < s.n; v += 8) {
+      const double a = a_row[v];
+      aq += a * s.Q[(size_t)v * KHP + hp];
+      ap += a * s.X[(size_t)v * KHP + hp];
+    }
+    scratch[t] = aq;
+    __syncthreads();
+    if (t < 32) { double z = 0.0; for (int q = 0; q < 8; ++q) z += scratch[t + 32 * q]; sAQ[t] = z; }
+    __syncthreads();
+    scratch[t] = ap;
+    __syncthreads();
+    if (t < 32) { double z = 0.0; for (int q = 0; q < 8; ++q) z += scratch[t + 32 * q]; sAP[t] = z; }
+    __syncthreads();
+  }
+  double* gA = s.W + (size_t)(s.n_pad + h) * s.ld;  // the right-hand-side row of W is free by now
+  double dot = 0.0;
+  for (int v = t; v < s.n; v += 256) {
+    const double* q = s.Q + (size_t)v * KHP;
+    const double* p = s.X + (size_t)v * KHP;
+    double g = q[h];
+    for (int hp = 0; hp < Kh; ++hp) g -= sAQ[hp] * p[hp] + sAP[hp] * q[hp];
+    gA[v] = g;
+    dot += a_row[v] * g;
+  }
+  dot = block_reduce(dot, scratch, [](double a, double b) { return a + b; });
+  for (int v = t; v < s.n; v += 256) grad_lbs[(size_t)v * Kh + h] = (float)(a_row[v] * (gA[v] - dot));
+}
+
+}  // namespace acfm
+
+using namespace acfm;
+
+extern "C" {
+
+size_t acfm_deform_solve_workspace_bytes(int V, int Kh) {
+  if (V <= 0 || Kh <= 0 || Kh > KHP) return 0;
+  return carve_solve(nullptr, V).bytes;
+}
+
+int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!L || !lbs || !P || !ws || V <= 0 || Kh <= 0 || Kh > KHP || V > 16384) return ACFM_E_BADARG;
+  SolveWs s = carve_solve(ws, V);
+  if (ws_bytes < s.bytes) return ACFM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(ACFM_PROF_SOLVE, st);
+  // the identity rows start as zero (k_solve_softmax writes their diagonal)
+  if (hipMemsetAsync(s.W + (size_t)(s.n_pad + NB) * s.ld, 0, sizeof(double) * (size_t)s.n_pad * s.ld, st) !=
+      hipSuccess)
+    return ACFM_E_LAUNCH;
+  hipLaunchKernelGGL(k_solve_softmax, dim3(KHP), dim3(256), 0, st, lbs, s, Kh);
+  hipLaunchKernelGGL(k_solve_gram_rows, dim3(s.n_pad), dim3(256), 0, st, L, s, Kh);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, s);
+  for (int k = 0; k < s.nblk; ++k) {
+    const int m = s.nblk - 1 - k;
+    hipLaunchKernelGGL(k_chol_step, dim3(m + 1, s.nblk + 1), dim3(256), 0, st, s, k);
+  }
+  hipLaunchKernelGGL((k_apply_R<false, 0>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)nullptr,
+                     (const float*)nullptr, Kh, s.X, P);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, size_t ws_bytes, float* grad_lbs,
+                               void* stream) {
+  if (!grad_P || !grad_lbs || !ws || V <= 0 || Kh <= 0 || Kh > KHP || V > 16384) return ACFM_E_BADARG;
+  SolveWs s = carve_solve(ws, V);
+  if (ws_bytes < s.bytes) return ACFM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(ACFM_PROF_SOLVE_BWD, st);
+  hipLaunchKernelGGL((k_apply_R<true, 2>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)nullptr, grad_P, Kh,
+                     s.Z, (float*)nullptr);
+  hipLaunchKernelGGL((k_apply_R<false, 1>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)s.Z,
+                     (const float*)nullptr, Kh, s.Q, (float*)nullptr);
+  hipLaunchKernelGGL(k_solve_bwd_lbs, dim3(Kh), dim3(256), 0, st, s, Kh, grad_lbs);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_host, void* stream) {
+  if (!ws || !info_host || V <= 0) return ACFM_E_BADARG;
+  SolveWs s = carve_solve(const_cast<void*>(ws), V);
+  if (ws_bytes < s.bytes) return ACFM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return ACFM_E_LAUNCH;
+  return ACFM_OK;
+}
+
+}  // extern "C"

@@ -6,11 +6,12 @@ cholesky_solve on B*T identical 642x642 systems.  Algebraically b = M v + A^T de
 
         pred_v_n = v + P delta_n,      P = M^-1 A^T   (V x K_h)
 
-P depends only on the handle weights (lbs) and on the no-grad Laplacian of the mean shape:
-it is factorised ONCE per optimiser step in fp64 (more accurate than the reference's own
-fp32 Cholesky) and applied per frame as a [V x K_h] . [K_h x 3] product.
-Gradients: d delta_n = P^T g_n, d v = sum_n g_n (L is a constant, geom_utils.py:245), and
-d lbs flows through the fp64 factorisation by autograd when lbs requires grad.
+P depends only on the handle weights (lbs) and on the no-grad Laplacian of the mean shape; both
+are learned (mesh_net.py:480, 543), so it is rebuilt ONCE per optimiser step: on the GPU by the
+blocked fp64 Cholesky of csrc/acfm_solve.hip (ops.deform_solve: more accurate than the
+reference's own fp32 Cholesky), and applied per frame as a [V x K_h] . [K_h x 3]
+product (ops.deform_apply).  Gradients: d delta_n = P^T g_n, d v = sum_n g_n (L is a constant,
+geom_utils.py:245), d lbs through the saved factor (acfm_deform_solve_backward).
 """
 import torch
 from torch import nn
@@ -40,40 +41,61 @@ def handle_matrix(lbs_logits):
 
 
 def solve_matrix(L, A):
-    """P = (L^T L + A^T A)^-1 A^T in fp64 via Cholesky (main.py:605-608 collapsed)."""
+    """P = (L^T L + A^T A)^-1 A^T in fp64 via torch.linalg (host tensors / cross-check of the
+    native kernel; main.py:605-608 collapsed)."""
     L64, A64 = L.double(), A.double()
     M = L64.t() @ L64 + A64.t() @ A64
     u = torch.linalg.cholesky(M)
     return torch.cholesky_solve(A64.t(), u)
 
 
+def _solve(L, lbs_logits):
+    if lbs_logits.is_cuda:
+        from . import ops
+        return ops.deform_solve(L, lbs_logits)
+    return solve_matrix(L, handle_matrix(lbs_logits)).float()
+
+
 class DeformSolver(nn.Module):
+    """mean_v / lbs_logits may be nn.Parameters (learned, as in the reference) or plain tensors."""
+
     def __init__(self, mean_v, faces, lbs_logits, method="cot"):
         super().__init__()
         self.method = method
-        self.register_buffer("mean_v", mean_v.detach().clone())
+        if isinstance(mean_v, nn.Parameter):
+            self.mean_v = mean_v
+        else:
+            self.register_buffer("mean_v", mean_v.detach().clone())
         self.register_buffer("faces", faces.detach().clone().long())
         if isinstance(lbs_logits, nn.Parameter):
             self.lbs = lbs_logits
         else:
             self.register_buffer("lbs", lbs_logits.detach().clone())
         self._P = None
-        self.refresh()
+        self._L = None
 
     def laplacian(self, mean_v=None):
-        v = self.mean_v if mean_v is None else mean_v.detach()
+        v = (self.mean_v if mean_v is None else mean_v).detach()
         return geom_utils.mesh_laplacian(_OneMesh(v, self.faces), self.method)
 
     def refresh(self, mean_v=None):
-        """Re-factorise after lbs (or the mean shape that defines L) changed: once per step."""
-        with torch.no_grad():
-            L = self.laplacian(mean_v)
-            self._P = solve_matrix(L, handle_matrix(self.lbs)).float()
-        return self._P
+        """Call after lbs or the mean shape (which defines L) changed, i.e. once per optimiser
+        step: the next solve_matrix() rebuilds L and re-factorises."""
+        self._P = None
+        self._L = self.laplacian(mean_v)
 
-    def solve_matrix(self, mean_v=None):
+    def solve_matrix(self):
+        """P [V,K_h]; one factorisation per refresh().  With lbs requiring grad (and grad mode on)
+        the factorisation is part of the autograd graph of this step."""
+        if self._L is None:
+            self._L = self.laplacian()
         if self.lbs.requires_grad and torch.is_grad_enabled():
-            return solve_matrix(self.laplacian(mean_v), handle_matrix(self.lbs)).float()
+            P = _solve(self._L, self.lbs)
+            self._P = P.detach()
+            return P
+        if self._P is None:
+            with torch.no_grad():
+                self._P = _solve(self._L, self.lbs)
         return self._P
 
     def forward(self, delta, mean_override=None):

@@ -59,8 +59,9 @@ class MultiframeStep(nn.Module):
         self.deform_emb.weight.data.zero_()                     # mesh_net.py:448-451
         self.deform_mirror_emb.weight.data.zero_()
         self.lbs = nn.Parameter(lbs_logits.detach().clone())    # mesh_net.py:543-544
+        self.mean_v = nn.Parameter(mean_v.detach().clone())     # mesh_net.py:480 (symmetrisation: identity here)
         self.register_buffer("faces1", faces.detach().clone().long())
-        self.solver = DeformSolver(mean_v, faces, self.lbs)
+        self.solver = DeformSolver(self.mean_v, faces, self.lbs)
         self.vert2kp = vert2kp
         self.renderer = NeuralRenderer(img_size)
         self.tex_renderer = NeuralRenderer(img_size)
@@ -142,7 +143,7 @@ class MultiframeStep(nn.Module):
             delta = ((1 - flag) * d0 + flag * d1) * o.optimize_deform_lr
         else:
             delta = delta_v_res
-        self.solver.refresh()                                    # lbs changed in the last optimiser step
+        self.solver.refresh()       # lbs / mean shape moved in the last optimiser step: one factorisation
         pred_v1 = self.solver(delta)                             # [N,V,3]
         pred_v = pred_v1.repeat(G, 1, 1)
         faces = self.faces1[None].expand(G * N, -1, -1)

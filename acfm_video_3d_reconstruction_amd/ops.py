@@ -106,6 +106,57 @@ def deform_apply(mean_v, P, delta):
     return _DeformApply.apply(mean_v, P, delta)
 
 
+class _DeformSolve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, L, lbs, check):
+        _lib.require_gpu(L, lbs)
+        l, b = _f32c(L.detach()), _f32c(lbs)
+        V, Kh = b.shape
+        if l.shape != (V, V):
+            raise ValueError("L must be [V,V] = [%d,%d], got %s" % (V, V, tuple(l.shape)))
+        if Kh > 32:
+            raise ValueError("at most 32 handles (got %d)" % Kh)
+        lib = _lib.lib()
+        nbytes = lib.acfm_deform_solve_workspace_bytes(V, Kh)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        P = torch.empty((V, Kh), dtype=torch.float32, device=b.device)
+        with torch.cuda.device(b.device):
+            st = _lib.cur_stream(b.device)
+            _lib.check(lib.acfm_deform_solve(_lib.ptr(l), _lib.ptr(b), V, Kh, _lib.ptr(P), _lib.ptr(ws), nbytes, st),
+                       "acfm_deform_solve")
+            if check:
+                import ctypes
+                info = ctypes.c_int(0)
+                _lib.check(lib.acfm_deform_solve_info(_lib.ptr(ws), nbytes, V, ctypes.byref(info), st),
+                           "acfm_deform_solve_info")
+                if info.value:
+                    raise RuntimeError("deform_solve: L^T L + A^T A is not positive definite "
+                                       "(pivot tile starting at row %d)" % (info.value - 1))
+        ctx.ws, ctx.dims = ws, (V, Kh)
+        return P
+
+    @staticmethod
+    def backward(ctx, g):
+        V, Kh = ctx.dims
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        g = _f32c(g)
+        gl = torch.empty((V, Kh), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_deform_solve_backward(_lib.ptr(g), V, Kh, _lib.ptr(ctx.ws), ctx.ws.numel(),
+                                                             _lib.ptr(gl), _lib.cur_stream(g.device)),
+                       "acfm_deform_solve_backward")
+        return None, gl, None
+
+
+def deform_solve(L, lbs_logits, check=False):
+    """P [V,K_h] = (L^T L + A^T A)^-1 A^T with A = softmax(lbs_logits, dim 0)^T: the reference's
+    per-frame Cholesky solve (multiframe/main.py:586-609) collapsed to one fp64 factorisation per
+    step.  L [V,V] dense Laplacian (no gradient), lbs_logits [V,K_h] (gradient supported).
+    check=True synchronises and raises if the matrix is not positive definite."""
+    return _DeformSolve.apply(L, lbs_logits, bool(check))
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod

@@ -67,6 +67,8 @@ const char* acfm_arch(void);         /* "gfx950" */
 #define ACFM_PROF_TEX_MSE_BWD 14
 #define ACFM_PROF_DEFORM 15
 #define ACFM_PROF_DEFORM_BWD 16
+#define ACFM_PROF_SOLVE 17
+#define ACFM_PROF_SOLVE_BWD 18
 #define ACFM_PROF_NKERNELS 24
 #define ACFM_PROF_RING 8192
 int acfm_prof_enable(int on);
@@ -95,6 +97,24 @@ int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, i
                       float* verts, void* stream);
 int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
                                int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
+
+/* ---- template deformation solve ------------------------------------------------------
+ * replaces the per-frame torch.cholesky / torch.cholesky_solve of multiframe/main.py:586-609
+ * (also optimization/main.py:474-496, nnutils/predictor.py:260-276): with A = softmax(lbs, dim 0)^T
+ * [K_h,V] (mesh_net.py:597-599) and the dense cotangent Laplacian L [V,V] of the mean shape,
+ *   P = (L^T L + A^T A)^-1 A^T   [V,K_h]
+ * by a blocked fp64 Cholesky on the matrix cores; once per optimiser step for all frames
+ * (pred_v_n = mean_v + P delta_n, acfm_deform_apply).  K_h <= 32.
+ * The workspace keeps the factor: acfm_deform_solve_backward turns grad_P [V,K_h] into
+ * grad_lbs [V,K_h] (L carries no gradient, geom_utils.py:245).  acfm_deform_solve_info copies
+ * the factorisation status to the host (0 = ok, else 1 + first row of the 32-row tile with a
+ * non-positive pivot; the reference's torch.cholesky raises there) and synchronises the stream. */
+size_t acfm_deform_solve_workspace_bytes(int V, int Kh);
+int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P, void* ws, size_t ws_bytes,
+                      void* stream);
+int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, size_t ws_bytes, float* grad_lbs,
+                               void* stream);
+int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_host, void* stream);
 
 /* ---- rasterisation workspace -------------------------------------------------------
  * Scratch of one render call of N meshes with V verts and F faces each at H x H pixels

@@ -180,6 +180,51 @@ def test_deform_apply_mfma_kernels(meshes):
     assert np.abs(out.numpy() - g["bird_k16_pred_v"]).max() < 2e-4
 
 
+def test_deform_solve_native(meshes):
+    """a8: the blocked fp64 Cholesky P = (L^T L + A^T A)^-1 A^T (csrc/acfm_solve.hip) and its
+    lbs gradient against an fp64 torch evaluation of the reference's expression."""
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    cases = [("bird", 16), ("horse", 15), ("cow", 32), ("horse", 3)]
+    for name, Kh in cases:
+        v, f = torch.from_numpy(meshes[name + "_v"]), torch.from_numpy(meshes[name + "_f"])
+        L = O.laplacian_cot(v.double(), f).float()
+        logits = torch.tensor(fps_lbs_logits(v.numpy(), Kh))
+        torch.manual_seed(Kh)
+        w = torch.randn(v.shape[0], Kh)
+        lg = logits.clone().to(d).requires_grad_(True)
+        P = ops.deform_solve(L.to(d), lg, check=True)
+        (P * w.to(d)).sum().backward()
+        l64 = logits.double().requires_grad_(True)
+        A = torch.softmax(l64, dim=0).t()
+        M = L.double().t() @ L.double() + A.t() @ A
+        ref = torch.cholesky_solve(A.t(), torch.linalg.cholesky(M))
+        (ref * w.double()).sum().backward()
+        scale = float(ref.abs().max())
+        assert float((P.detach().cpu().double() - ref.detach()).abs().max()) < 1e-5 * scale, (name, Kh)
+        gs = float(l64.grad.abs().max())
+        assert float((lg.grad.cpu().double() - l64.grad).abs().max()) < 1e-4 * gs, (name, Kh)
+    # small sizes that are not a multiple of the tile: V = 50, 33, 32, 5
+    for V, Kh in ((50, 7), (33, 4), (32, 2), (5, 1)):
+        torch.manual_seed(V)
+        Lr = torch.randn(V, V)
+        logits = torch.randn(V, Kh)
+        lg = logits.clone().to(d).requires_grad_(True)
+        P = ops.deform_solve(Lr.to(d), lg, check=True)
+        P.square().sum().backward()
+        l64 = logits.double().requires_grad_(True)
+        A = torch.softmax(l64, dim=0).t()
+        M = Lr.double().t() @ Lr.double() + A.t() @ A
+        ref = torch.cholesky_solve(A.t(), torch.linalg.cholesky(M))
+        ref.square().sum().backward()
+        np.testing.assert_allclose(P.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), l64.grad.numpy(), rtol=1e-3, atol=1e-5 * float(l64.grad.abs().max()))
+    # a matrix that is not positive definite is reported (the reference's torch.cholesky raises)
+    with pytest.raises(RuntimeError):
+        ops.deform_solve(torch.zeros(40, 40, device=d), torch.full((40, 2), float("nan"), device=d), check=True)
+
+
 def test_mesh_priors_hip(meshes):
     """a9 / a14 / a15 on the GPU: cot Laplacian, Laplacian smoothing (cot + uniform) and edge rigidity
     through the reference-shaped API, against the reference's golden outputs and the oracle."""
