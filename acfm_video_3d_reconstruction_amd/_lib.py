@@ -115,3 +115,19 @@ def require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError("acfm_video_3d_reconstruction_amd ops run on the GPU only "
                                "(got a %s tensor); there is no CPU fallback" % t.device)
+
+
+_CONSTS = {}
+
+
+def const(values, device, dtype=None):
+    """Small constant tensor on `device`, uploaded once per (values, device, dtype): a fresh
+    torch.tensor(..., device=cuda) is a pageable host-to-device copy, which is not allowed while
+    a stream is being captured into a hipGraph."""
+    import torch
+    dtype = dtype or torch.float32
+    key = (tuple(values), str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t

@@ -16,10 +16,20 @@ def decode_cameras(cam_emb, scale_lr_decay=1.0):
     return torch.cat([scales, cam_emb[..., 1:3], quats], dim=-1)
 
 
+_MIRROR_Q = {}
+
+
+def _mirror_rotation(device):
+    """Quaternion of diag(-1, 1, -1) (main.py:104); built once per device, outside any capture."""
+    key = str(device)
+    if key not in _MIRROR_Q:
+        diag = torch.diag(torch.tensor([-1., 1., -1.]))[None]
+        _MIRROR_Q[key] = matrix_to_quaternion(diag).to(device)
+    return _MIRROR_Q[key]
+
+
 def _mirror_quat(q):
-    quat = standardize_quaternion(q)
-    diag = torch.diag(torch.tensor([-1., 1., -1.], device=q.device))[None]
-    return quaternion_multiply(matrix_to_quaternion(diag), quat)
+    return quaternion_multiply(_mirror_rotation(q.device), standardize_quaternion(q))
 
 
 def _mirrored_pose(sfm_pose):

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import ops
+from .. import _lib, ops
 from . import geom_utils
 
 
@@ -64,7 +64,7 @@ _CONJ_SIGN = (1.0, -1.0, -1.0, -1.0)
 
 def quat_conj(q):
     """loss_utils.py:35-36: (w, x, y, z) -> (w, -x, -y, -z) on [B,N,4]."""
-    return q * q.new_tensor(_CONJ_SIGN)
+    return q * _lib.const(_CONJ_SIGN, q.device, q.dtype)
 
 
 def quat2ang(q):

@@ -4,6 +4,8 @@ through verts_packed / faces_packed / edges_packed / verts_padded / num_verts_pe
 isempty / device / len()."""
 import torch
 
+from .. import _lib
+
 # edges_packed of a batch is a sort + unique over 3*N*F pairs; the reference rebuilds Meshes every
 # step from the same faces tensor, so the result is memoised on (storage, shape, version).
 _EDGE_CACHE = {}
@@ -46,10 +48,10 @@ class Meshes:
         return self._faces_list
 
     def num_verts_per_mesh(self):
-        return torch.tensor([v.shape[0] for v in self._verts_list], device=self.device, dtype=torch.int64)
+        return _lib.const([v.shape[0] for v in self._verts_list], self.device, torch.int64)
 
     def num_faces_per_mesh(self):
-        return torch.tensor([f.shape[0] for f in self._faces_list], device=self.device, dtype=torch.int64)
+        return _lib.const([f.shape[0] for f in self._faces_list], self.device, torch.int64)
 
     def _equal_sized(self):
         return (len({v.shape[0] for v in self._verts_list}) == 1 and
@@ -85,7 +87,8 @@ class Meshes:
 
     def verts_packed_to_mesh_idx(self):
         n = self.num_verts_per_mesh()
-        return torch.repeat_interleave(torch.arange(len(self), device=self.device), n)
+        total = sum(v.shape[0] for v in self._verts_list)     # known on the host: no device sync
+        return torch.repeat_interleave(torch.arange(len(self), device=self.device), n, output_size=total)
 
     def faces_packed(self):
         if "faces_packed" not in self._cache:

@@ -1,6 +1,7 @@
 """pytorch3d.transforms functions used by the reference's camera mirroring
 (multiframe/main.py:97-125): real-first quaternions."""
 import torch
+from .. import _lib
 
 
 def standardize_quaternion(quaternions):
@@ -23,7 +24,7 @@ def quaternion_multiply(a, b):
 
 
 def quaternion_invert(quaternion):
-    return quaternion * quaternion.new_tensor([1, -1, -1, -1])
+    return quaternion * _lib.const((1.0, -1.0, -1.0, -1.0), quaternion.device, quaternion.dtype)
 
 
 def _copysign(a, b):

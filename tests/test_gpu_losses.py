@@ -327,3 +327,65 @@ def test_multiframe_step_harness(meshes):
     assert set(["mask", "sil_cons", "rigid", "triangle", "camera_loss", "probs", "tex_mse"]) <= set(terms)
     total2, _ = step(batch, delta, drop_deform=True, detach_camera=True)     # train_utils.py:252's call
     assert torch.isfinite(total2)
+
+
+def test_multiframe_step_hipgraph_matches_eager(meshes):
+    """The whole optimiser step (forward, backward, Adam) captured as one hipGraph (graphed.py)
+    follows the eager trajectory: same losses, same parameters after several steps on changing
+    inputs (tolerance: float atomics in the backward kernels make neither run bit-reproducible)."""
+    import copy
+    from acfm_video_3d_reconstruction_amd import image_utils as IU
+    from acfm_video_3d_reconstruction_amd.graphed import GraphedStep
+    from acfm_video_3d_reconstruction_amd.multiframe_step import MultiframeStep
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
+    d = _d()
+    torch.manual_seed(1)
+    rng = np.random.default_rng(1)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    B, T, G, H, Kh = 2, 2, 3, 64, 15
+    N = B * T
+    step_e = MultiframeStep(torch.tensor(v, device=d), torch.tensor(f, device=d),
+                            torch.tensor(fps_lbs_logits(v, Kh), device=d), num_training_frames=10, img_size=H,
+                            num_guesses=G, num_lbs=Kh, scale_lr_decay=1.0).to(d)
+    step_g = copy.deepcopy(step_e)
+    gt_cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
+    with torch.no_grad():
+        gt_mask, _ = step_e.renderer(step_e.solver.mean_v[None].repeat(N, 1, 1),
+                                     step_e.faces1[None].expand(N, -1, -1), gt_cams)
+        gt_mask = (gt_mask > 0.5).float()
+
+    def make_inputs(seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return dict(masks=gt_mask, edts_barrier=IU.compute_dt(gt_mask, norm=False)[:, None].contiguous(),
+                    boundaries=IU.compute_boundaries(gt_mask),
+                    frames_idx=torch.randint(0, 10, (B, T), generator=g).to(d),
+                    mirror_flag=torch.randint(0, 2, (N,), generator=g).to(d),
+                    transforms=torch.tensor([[1., 0, 0, 0]] * N, device=d),
+                    optical_flows=torch.randn(B, T, H, H, 2, generator=g).to(d),
+                    delta=(0.01 * torch.randn(N, Kh, 3, generator=g)).to(d),
+                    tex=torch.rand(N, f.shape[0], 4, 4, 3, generator=g).to(d),
+                    imgs=torch.rand(N, 3, H, H, generator=g).to(d))
+
+    def fn(step):
+        return lambda i: step(i, i["delta"], textures=i["tex"], imgs=i["imgs"])[0]
+
+    opt_g = torch.optim.Adam(step_g.parameters(), lr=1e-3, capturable=True)
+    runner = GraphedStep(fn(step_g), opt_g, make_inputs(0), grad_inputs=("delta", "tex"))
+    for pe, pg in zip(step_e.parameters(), step_g.parameters()):       # construction does not train
+        assert torch.equal(pe, pg)
+    opt_e = torch.optim.Adam(step_e.parameters(), lr=1e-3, capturable=True)
+    for it in range(4):
+        inp = make_inputs(it)
+        loss_g = runner(inp).item()
+        gd = runner.grads["delta"].clone()
+        opt_e.zero_grad(set_to_none=True)
+        ie = {k: (t.clone().requires_grad_(True) if k in ("delta", "tex") else t) for k, t in inp.items()}
+        loss_e = fn(step_e)(ie)
+        loss_e.backward()
+        opt_e.step()
+        assert abs(loss_g - loss_e.item()) < 2e-3 * abs(loss_e.item()), (it, loss_g, loss_e.item())
+        np.testing.assert_allclose(gd.cpu().numpy(), ie["delta"].grad.cpu().numpy(), rtol=5e-2,
+                                   atol=2e-3 * float(ie["delta"].grad.abs().max()))
+    for (name, pe), pg in zip(step_e.named_parameters(), step_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=0,
+                                   atol=2e-3 * max(1e-3, float(pe.abs().max())), err_msg=name)

@@ -13,7 +13,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--B", type=int, default=8); p.add_argument("--G", type=int, default=6)
 p.add_argument("--img", type=int, default=256); p.add_argument("--iters", type=int, default=10)
 p.add_argument("--mesh", default="horse"); p.add_argument("--tex", type=int, default=1)
-p.add_argument("--torch-profile", action="store_true")
+p.add_argument("--torch-profile", action="store_true"); p.add_argument("--graph", action="store_true")
 a = p.parse_args()
 d = torch.device("cuda:0")
 m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz")); v, f = m[a.mesh + "_v"], m[a.mesh + "_f"]
@@ -32,21 +32,33 @@ batch = dict(masks=gt, edts_barrier=IU.compute_dt(gt, norm=False)[:, None].conti
 delta = (0.01 * torch.randn(N, Kh, 3, device=d)).requires_grad_(True)
 tex = torch.rand(N, f.shape[0], 6, 6, 3, device=d, requires_grad=True) if a.tex else None
 imgs = torch.rand(N, 3, H, H, device=d) if a.tex else None
-opt = torch.optim.Adam(list(step.parameters()) + [delta] + ([tex] if a.tex else []), lr=1e-4)
-def one():
-    opt.zero_grad(set_to_none=True)
-    loss, _ = step(batch, delta, textures=tex, imgs=imgs)
-    loss.backward(); opt.step()
+if a.graph:
+    from acfm_video_3d_reconstruction_amd.graphed import GraphedStep
+    opt = torch.optim.Adam(list(step.parameters()), lr=1e-4, capturable=True)
+    inputs = dict(batch, delta=delta.detach())
+    if a.tex: inputs.update(tex=tex.detach(), imgs=imgs)
+    runner = GraphedStep(lambda i: step(i, i["delta"], textures=i.get("tex"), imgs=i.get("imgs"))[0], opt, inputs,
+                         grad_inputs=("delta", "tex") if a.tex else ("delta",))
+    def one():
+        runner(inputs)
+else:
+    opt = torch.optim.Adam(list(step.parameters()) + [delta] + ([tex] if a.tex else []), lr=1e-4)
+    def one():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = step(batch, delta, textures=tex, imgs=imgs)
+        loss.backward(); opt.step()
 for _ in range(3): one()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): one()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
-lib = _lib.lib(); lib.acfm_prof_enable(1)
-for _ in range(a.iters): one()
-torch.cuda.synchronize()
-prof = _lib.prof_collect(); lib.acfm_prof_enable(0)
-ks = sum(ms for ms, _ in prof.values()) / a.iters
-print("multiframe step B=%d T=2 G=%d (%d meshes) @%d, mesh=%s tex=%d: %.2f ms/step (%.0f clip-frames/s), HIP kernels %.2f ms" % (
+prof, ks = {}, float("nan")
+if not a.graph:                          # the hipEvent brackets are not part of a captured graph
+    lib = _lib.lib(); lib.acfm_prof_enable(1)
+    for _ in range(a.iters): one()
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect(); lib.acfm_prof_enable(0)
+    ks = sum(ms for ms, _ in prof.values()) / a.iters
+print(("hipGraph " if a.graph else "eager ") + "multiframe step B=%d T=2 G=%d (%d meshes) @%d, mesh=%s tex=%d: %.2f ms/step (%.0f clip-frames/s), HIP kernels %.2f ms" % (
     B, G, G * N, H, a.mesh, a.tex, 1e3 * dt, N / dt, ks))
 for k, (ms, c) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
     print("   %-24s %8.1f us/step  x%.0f" % (k, 1e3 * ms / a.iters, c / a.iters))
