@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-oracle time budget")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-lean", action="store_true", help="skip the nearest-plane-only comparison run")
+    p.add_argument("--tex-stream", type=int, default=0,
+                   help="texture branch on its own HIP stream (measured slower: 1.34 vs 1.26 ms/step)")
     return p.parse_args()
 
 
@@ -121,14 +123,28 @@ def main():
 
     params = [delta, cams, mean_p, atlas]
 
+    side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
+
     def step(ren=renderer):
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
+        tex_term = None
+        if side is not None:
+            # experiment (off by default): the texture branch reads detached geometry only
+            # (main.py:627-636), so it can run on its own HIP stream beside the silhouette kernels
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
+                tex_term = 0.5 * L.masked_texture_mse(tex, imgs_gt, gt_mask).mean()  # main.py:655-662
         mask, p2f = ren(pred_v, faces, cams)                             # a3
         l1, iou, e = L.fused_silhouette_losses(mask, gt_mask, edt)       # a10, a11
         proj = ren.project_points(pred_v, cams)                          # a2
         bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
         total = (l1 + 0.1 * e + 0.1 * bdt).mean()
-        if a.tex:
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            total = total + tex_term
+        elif a.tex:
             tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
             total = total + 0.5 * L.masked_texture_mse(tex, imgs_gt, gt_mask).mean()     # main.py:655-662
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
