@@ -369,11 +369,14 @@ def test_multiframe_step_hipgraph_matches_eager(meshes):
     def fn(step):
         return lambda i: step(i, i["delta"], textures=i["tex"], imgs=i["imgs"])[0]
 
-    opt_g = torch.optim.Adam(step_g.parameters(), lr=1e-3, capturable=True)
+    # SGD + momentum: the update is linear in the gradients, so the run-to-run noise of the float
+    # atomics stays small (Adam turns a sign flip of a ~0 gradient into a full lr-sized step)
+    opt_g = torch.optim.SGD(step_g.parameters(), lr=1e-3, momentum=0.9)
+    p0 = [q.detach().clone() for q in step_e.parameters()]
     runner = GraphedStep(fn(step_g), opt_g, make_inputs(0), grad_inputs=("delta", "tex"))
     for pe, pg in zip(step_e.parameters(), step_g.parameters()):       # construction does not train
         assert torch.equal(pe, pg)
-    opt_e = torch.optim.Adam(step_e.parameters(), lr=1e-3, capturable=True)
+    opt_e = torch.optim.SGD(step_e.parameters(), lr=1e-3, momentum=0.9)
     for it in range(4):
         inp = make_inputs(it)
         loss_g = runner(inp).item()
@@ -386,6 +389,9 @@ def test_multiframe_step_hipgraph_matches_eager(meshes):
         assert abs(loss_g - loss_e.item()) < 2e-3 * abs(loss_e.item()), (it, loss_g, loss_e.item())
         np.testing.assert_allclose(gd.cpu().numpy(), ie["delta"].grad.cpu().numpy(), rtol=5e-2,
                                    atol=2e-3 * float(ie["delta"].grad.abs().max()))
-    for (name, pe), pg in zip(step_e.named_parameters(), step_g.parameters()):
-        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=0,
-                                   atol=2e-3 * max(1e-3, float(pe.abs().max())), err_msg=name)
+    moved = 0
+    for (name, pe), pg, q0 in zip(step_e.named_parameters(), step_g.parameters(), p0):
+        de, dg = (pe.detach() - q0).cpu().numpy(), (pg.detach() - q0).cpu().numpy()
+        moved += int(np.abs(de).max() > 0)
+        np.testing.assert_allclose(dg, de, rtol=0, atol=2e-2 * float(np.abs(de).max()) + 1e-10, err_msg=name)
+    assert moved >= 5
