@@ -13,7 +13,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--B", type=int, default=8); p.add_argument("--G", type=int, default=6)
 p.add_argument("--img", type=int, default=256); p.add_argument("--iters", type=int, default=10)
 p.add_argument("--mesh", default="horse"); p.add_argument("--tex", type=int, default=1)
-p.add_argument("--torch-profile", action="store_true"); p.add_argument("--graph", action="store_true")
+p.add_argument("--torch-profile", action="store_true"); p.add_argument("--graph", action="store_true"); p.add_argument("--series", type=int, default=0)
 a = p.parse_args()
 d = torch.device("cuda:0")
 m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz")); v, f = m[a.mesh + "_v"], m[a.mesh + "_f"]
@@ -48,6 +48,11 @@ else:
         loss, _ = step(batch, delta, textures=tex, imgs=imgs)
         loss.backward(); opt.step()
 for _ in range(3): one()
+if a.series:
+    ts = []
+    for _ in range(a.series):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); one(); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+    print("per-step ms:", " ".join("%.2f" % t for t in ts))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): one()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
