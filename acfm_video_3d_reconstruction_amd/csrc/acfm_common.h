@@ -42,8 +42,9 @@ struct RasterWs {
   int4* vidx;      // [N,F] (i0,i1,i2,-)
   float4* mbox;    // [N]   union of the face boxes
   float* grad_ndc; // [N,V,2]
-  int* tile_cnt;   // [N,tiles^2] faces whose box meets the tile (cost estimate for scheduling)
-  int* order;      // [N*tiles^2] heavy-first visiting order of (mesh, tile) per XCD group
+  int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
+  int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
+  unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every 32x32-pixel coarse tile (words = ceil(F/64) u64)
   size_t bytes;
 };
 
@@ -61,9 +62,11 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
   w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
-  const size_t tt = (size_t)((H + 15) / 16) * ((H + 15) / 16);
+  const size_t tt = (size_t)((H + 7) / 8) * ((H + 7) / 8);  // 8x8-pixel blocks (RBLK)
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
+  const size_t ct = (size_t)((H + 31) / 32) * ((H + 31) / 32), words = ((size_t)F + 63) / 64;
+  w.cmask = (unsigned*)(p + o); o += align256(sizeof(unsigned) * 2 * (size_t)N * ct * words);
   w.bytes = o;
   return w;
 }

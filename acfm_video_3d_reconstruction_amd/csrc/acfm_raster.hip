@@ -8,10 +8,11 @@
 // Design:
 //   * k_setup: one workgroup per mesh projects the V vertices into LDS (weak-perspective
 //     camera, y flip, view transform) and writes per-face records + blur-expanded boxes.
-//   * k_raster_fwd / k_sil_bwd share one skeleton: a 256-thread workgroup owns a 16x16 pixel
-//     tile, each wave64 an 8x8 pixel block.  Faces are binned against the tile with wave
-//     ballots into an LDS candidate list (deterministic, face-ordered, one barrier per 256
-//     faces); every lane then walks the list with LDS broadcast reads.
+//   * k_raster_fwd / k_sil_bwd share one skeleton: a ONE-WAVE workgroup owns an 8x8 pixel
+//     block (four 4x4 blocks, one per 16-lane group).  Faces are binned against the block with
+//     wave ballots into an LDS candidate list (deterministic, face-ordered, no barriers); the
+//     groups then walk their own sub-lists.  (A 256-thread workgroup per 16x16 tile sharing
+//     one list finished only when its slowest 8x8 block did: 25 % of the wave slots idled.)
 //   * forward, K > 1: every lane keeps its pixel's K nearest (depth|face) keys and blend
 //     factors SORTED in registers (bubble-through insertion on static register indices): no
 //     per-pixel LDS or memory lists (4 waves/SIMD instead of 2), no final sort, the blend
@@ -26,11 +27,15 @@
 
 namespace acfm {
 
-constexpr int TILE = 16;      // pixels per tile side (PyTorch3D's auto bin size at 128/256)
-constexpr int TPB = 256;      // threads per workgroup = TILE*TILE
-constexpr int CAP = 320;      // LDS candidate-list capacity (walked early when it could overflow)
+constexpr int RBLK = 8;       // pixels per block side: one wave64 per block
+constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
+constexpr int RCAP = 128;     // LDS candidate-list capacity of a block (walked early when it could overflow)
+constexpr int TPB = 256;      // threads per workgroup of the per-mesh kernels (setup, projection)
 constexpr unsigned long long KEY_NONE = ~0ull;
-constexpr int SETUP_LDS_TILES = 4096;  // tile counters kept in LDS up to 1024x1024 images
+constexpr int SETUP_LDS_TILES = 4096;  // block counters kept in LDS up to 512x512 images
+constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
+constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
+constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
 
 // ------------------------------------------------------------------------------- setup
 // mode 0: verts are world coordinates -> project with cams, flip y   (nmr.py:145-149)
@@ -39,15 +44,23 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
                                                const float* __restrict__ cams, int V, int F, int H,
                                                float offset_z, int mode, float margin, RasterWs ws) {
-  extern __shared__ float s_v[];  // [V][3] then, if it fits, [tiles^2] int tile counters
+  extern __shared__ float s_v[];  // [V][3], then (if they fit) [blocks^2] int counters and the coarse masks
   __shared__ float s_red[4][4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* cam = cams ? cams + 7 * (size_t)n : nullptr;
-  const int tiles_ = (H + TILE - 1) / TILE, tt_ = tiles_ * tiles_;
+  const int tiles_ = (H + RBLK - 1) / RBLK, tt_ = tiles_ * tiles_;
   const bool lds_cnt = tt_ <= SETUP_LDS_TILES;
   int* s_cnt = reinterpret_cast<int*>(s_v + 3 * V);
   if (lds_cnt)
     for (int i = tid; i < tt_; i += TPB) s_cnt[i] = 0;
+  // coarse face masks: bit f of row (cty, ctx) <=> the box of face f may touch that 32x32 tile
+  const int ctiles_ = (H + CTILE - 1) / CTILE, mwords = 2 * ((F + 63) / 64);  // u32 words per row
+  const size_t mask_n = (size_t)ctiles_ * ctiles_ * mwords;
+  const bool lds_mask = mask_n * sizeof(unsigned) <= (size_t)SETUP_LDS_MASK_BYTES;
+  unsigned* g_mask = ws.cmask + (size_t)n * mask_n;                    // zeroed by the host if !lds_mask
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_cnt + (lds_cnt ? tt_ : 0));
+  if (lds_mask)
+    for (size_t i = tid; i < mask_n; i += TPB) s_mask[i] = 0u;
   for (int v = tid; v < V; v += TPB) {
     const float* x = verts + ((size_t)n * V + v) * 3;
     float px, py, pz;
@@ -90,18 +103,23 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
     if (!degenerate) {
-      // cost estimate for heavy-first scheduling: +1 on every tile the box may touch
+      // cost estimate for heavy-first scheduling: +1 on every 8x8 block the box may touch
       // (pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack)
-      const int tiles = (H + TILE - 1) / TILE;
+      const int tiles = (H + RBLK - 1) / RBLK;
       const float hf = (float)H;
       int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
       int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
       int ya = (int)floorf(hf - 1.0f - ((b.w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
       int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
       if (xb >= 0 && yb >= 0 && xa < H && ya < H) {
-        xa = max(xa, 0) / TILE; ya = max(ya, 0) / TILE;
-        xb = min(xb, H - 1) / TILE; yb = min(yb, H - 1) / TILE;
-        if ((xb - xa + 1) * (yb - ya + 1) <= 64)
+        xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
+        unsigned* mrow = lds_mask ? s_mask : g_mask;
+        const unsigned bit = 1u << (f & 31);
+        for (int cy = ya / CTILE; cy <= yb / CTILE; ++cy)
+          for (int cx = xa / CTILE; cx <= xb / CTILE; ++cx)
+            atomicOr(&mrow[(size_t)(cy * ctiles_ + cx) * mwords + (f >> 5)], bit);
+        xa /= RBLK; ya /= RBLK; xb /= RBLK; yb /= RBLK;
+        if ((xb - xa + 1) * (yb - ya + 1) <= 256)
           for (int ty = ya; ty <= yb; ++ty)
             for (int tx = xa; tx <= xb; ++tx) {
               if (lds_cnt) atomicAdd(&s_cnt[ty * tiles + tx], 1);
@@ -116,6 +134,8 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   __syncthreads();
   if (lds_cnt)
     for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i];
+  if (lds_mask)
+    for (size_t i = tid; i < mask_n; i += TPB) g_mask[i] = s_mask[i];
   if (tid == 0) {
     for (int i = 1; i < 4; ++i) {
       bx0 = fminf(bx0, s_red[i][0]); bx1 = fmaxf(bx1, s_red[i][1]);
@@ -126,13 +146,13 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
 }
 
 // ------------------------------------------------------------------------------- scheduling
-// Heavy-first order.  Per-tile work is heavy-tailed (dense clusters of tiny faces: a tile can
-// take 20x the average), so every XCD group visits its (mesh, tile) entries in descending cost
-// class; the long tiles start first and the short ones fill in behind them.
-// Entry e of group g  <->  mesh (e / tt) * G + g, tile e % tt   (G = 8 groups if N % 8 == 0, else 1).
-constexpr int NCLASS = 7;
+// Heavy-first order.  Per-block work is heavy-tailed (dense clusters of tiny faces: a block can
+// take 20x the average), so every XCD group visits its (mesh, block) entries in descending cost
+// class; the long blocks start first and the short ones fill in behind them.
+// Entry e of group g  <->  mesh (e / tt) * G + g, block e % tt   (G = 8 groups if N % 8 == 0, else 1).
+constexpr int NCLASS = 8;
 __device__ __forceinline__ int cost_class(int c) {
-  return c >= 192 ? 0 : c >= 128 ? 1 : c >= 96 ? 2 : c >= 64 ? 3 : c >= 32 ? 4 : c >= 1 ? 5 : 6;
+  return c >= 160 ? 0 : c >= 112 ? 1 : c >= 80 ? 2 : c >= 56 ? 3 : c >= 36 ? 4 : c >= 20 ? 5 : c >= 1 ? 6 : 7;
 }
 __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
   __shared__ int s_hist[NCLASS], s_base[NCLASS];
@@ -186,13 +206,13 @@ struct Tile {
   float t_xmin, t_xmax, t_ymin, t_ymax;
 };
 
-// Workgroup -> (mesh, tile) through the heavy-first order of its XCD group.  Workgroups are
-// dealt round-robin over the 8 XCDs, so with N % 8 == 0 group g = b % 8 owns the meshes
-// n % 8 == g (one XCD's L2 then holds the records of the meshes it renders).  Pure speed: any
-// mapping gives the same result.
+// Workgroup (= one wave) -> (mesh, 8x8 block) through the heavy-first order of its XCD group.
+// Workgroups are dealt round-robin over the 8 XCDs, so with N % 8 == 0 group g = b % 8 owns the
+// meshes n % 8 == g (one XCD's L2 then holds the records of the meshes it renders).  Pure speed:
+// any mapping gives the same result.
 __device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
   Tile t;
-  const int tiles = (H + TILE - 1) / TILE;
+  const int tiles = (H + RBLK - 1) / RBLK;
   const int tt = tiles * tiles;
   const unsigned b = blockIdx.x;
   int n, tl;
@@ -207,28 +227,27 @@ __device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
     tl = e % tt;
   }
   t.n = n;
-  t.tid = threadIdx.x; t.wv = t.tid >> 6; t.lane = t.tid & 63;
+  t.tid = threadIdx.x; t.wv = 0; t.lane = t.tid & 63;
   const int ty = tl / tiles, tx = tl % tiles;
-  // wave = 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row)
+  // the 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row)
   const int grp = t.lane >> 4, j = t.lane & 15;
-  t.yi = ty * TILE + (t.wv >> 1) * 8 + (grp >> 1) * 4 + (j >> 2);
-  t.xi = tx * TILE + (t.wv & 1) * 8 + (grp & 1) * 4 + (j & 3);
+  t.yi = ty * RBLK + (grp >> 1) * 4 + (j >> 2);
+  t.xi = tx * RBLK + (grp & 1) * 4 + (j & 3);
   t.valid = (t.yi < H) && (t.xi < H);
   t.yf = pix_to_ndc(H - 1 - t.yi, H);
   t.xf = pix_to_ndc(H - 1 - t.xi, H);
   t.pix = ((size_t)n * H + t.yi) * H + t.xi;
-  // tile extent in NDC (pixel centres; x/y decrease with the pixel index)
-  t.t_xmax = pix_to_ndc(H - 1 - tx * TILE, H); t.t_xmin = pix_to_ndc(H - 1 - (tx * TILE + TILE - 1), H);
-  t.t_ymax = pix_to_ndc(H - 1 - ty * TILE, H); t.t_ymin = pix_to_ndc(H - 1 - (ty * TILE + TILE - 1), H);
+  // block extent in NDC (pixel centres; x/y decrease with the pixel index)
+  t.t_xmax = pix_to_ndc(H - 1 - tx * RBLK, H); t.t_xmin = pix_to_ndc(H - 1 - (tx * RBLK + RBLK - 1), H);
+  t.t_ymax = pix_to_ndc(H - 1 - ty * RBLK, H); t.t_ymin = pix_to_ndc(H - 1 - (ty * RBLK + RBLK - 1), H);
   return t;
 }
 
 struct CandList {
-  float4 box[CAP], a[CAP], b[CAP];
-  float2 c[CAP];    // (z2, area)
-  int fid[CAP];
-  unsigned short sub[16][CAP]; // per 16-lane group (4 per wave): candidates meeting its 4x4 pixels
-  int wcnt[2][4];
+  float4 box[RCAP], a[RCAP], b[RCAP];
+  float2 c[RCAP];    // (z2, area)
+  int fid[RCAP];
+  unsigned short sub[4][RCAP]; // per 16-lane group: candidates meeting its 4x4 pixels
 };
 
 struct Cand {
@@ -284,7 +303,7 @@ __device__ __forceinline__ unsigned edge_cull4(const float4 a, const float4 b, f
 // were measured slower with it (+7 %, +2 %).
 template <bool EDGE_CULL, class Body>
 __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int list_n, float blur,
-                                          unsigned short* wl /* [CAP] of this wave, EDGE_CULL only */,
+                                          unsigned short* wl /* [RCAP], EDGE_CULL only */,
                                           Body&& body) {
   const int by = (t.yi & ~7), bx = (t.xi & ~7);
   const int grp = t.lane >> 4;
@@ -293,7 +312,7 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   const float xa1 = pix_to_ndc(H - 1 - (bx + 4), H), xi1 = pix_to_ndc(H - 1 - (bx + 7), H);
   const float ya0 = pix_to_ndc(H - 1 - by, H), yi0 = pix_to_ndc(H - 1 - (by + 3), H);
   const float ya1 = pix_to_ndc(H - 1 - (by + 4), H), yi1 = pix_to_ndc(H - 1 - (by + 7), H);
-  unsigned short* sub0 = L.sub[t.wv * 4];
+  unsigned short* sub0 = L.sub[0];
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
   if constexpr (!EDGE_CULL) {
@@ -308,10 +327,10 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
       }
       const unsigned long long b0 = __ballot(hx0 & hy0), b1 = __ballot(hx1 & hy0);
       const unsigned long long b2 = __ballot(hx0 & hy1), b3 = __ballot(hx1 & hy1);
-      if (hx0 & hy0) sub0[0 * CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (hx1 & hy0) sub0[1 * CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (hx0 & hy1) sub0[2 * CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (hx1 & hy1) sub0[3 * CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (hx0 & hy0) sub0[0 * RCAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
+      if (hx1 & hy0) sub0[1 * RCAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
+      if (hx0 & hy1) sub0[2 * RCAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
+      if (hx1 & hy1) sub0[3 * RCAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   } else {
@@ -352,10 +371,10 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
       }
       const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
       const unsigned long long b2 = __ballot(k2), b3 = __ballot(k3);
-      if (k0) sub0[0 * CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (k1) sub0[1 * CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (k2) sub0[2 * CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (k3) sub0[3 * CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (k0) sub0[0 * RCAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
+      if (k1) sub0[1 * RCAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
+      if (k2) sub0[2 * RCAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
+      if (k3) sub0[3 * RCAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   }
@@ -365,7 +384,7 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int my_n = (grp == 0) ? n0 : (grp == 1) ? n1 : (grp == 2) ? n2 : n3;
-  const unsigned short* sub = sub0 + grp * CAP;
+  const unsigned short* sub = sub0 + grp * RCAP;
   // a group that has run out of faces (or has none) keeps loading its last (or the tile's
   // first) record: harmless, the lanes are masked by `have`.  (Prefetching the next record one
   // iteration ahead was measured: +16 VGPRs, no change in time.)
@@ -379,52 +398,98 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   }
 }
 
-// Bins the F faces of mesh t.n against the tile and calls walk(count) (all threads, uniform)
-// whenever the LDS list is complete or could overflow.  WITH_VIDX also stages the vertex ids.
-template <bool WITH_VIDX, class Walk>
-__device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, CandList& L,
-                                             int4* s_vidx, Walk&& walk) {
+// Bins the faces of mesh t.n against the wave's 8x8 block and calls walk(count) whenever the LDS
+// list is complete or could overflow.  The faces come from the bitmask of the block's 32x32
+// coarse tile (k_setup): lane i expands mask word i into the wave's face-id list (ascending), then
+// 64 ids per round lane i tests face i's box; survivors are compacted with one ballot, face
+// order kept.  No barriers: the workgroup is one wave.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+template <class Walk>
+__device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, CandList& L,
+                                             int* s_fl /* [FLCAP] */, Walk&& walk) {
   const float4 mb = ws.mbox[t.n];
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
+  const unsigned long long lt = (1ull << t.lane) - 1ull;
+  const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
+  const int cty = (t.yi & ~7) / CTILE, ctx = (t.xi & ~7) / CTILE;
+  const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(ws.cmask) +
+                                   ((size_t)t.n * ctiles * ctiles + (size_t)cty * ctiles + ctx) * words;
   int list_n = 0;
-  const int rounds = (F + TPB - 1) / TPB;
-  for (int r = 0; r < rounds; ++r) {
-    const int f = r * TPB + t.tid;
-    bool pass = false;
-    float4 b = make_float4(0, 0, 0, 0);
-    if (f < F) {
-      b = ws.box[(size_t)t.n * F + f];
-      pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
+  // one loop with a single walk() site (the walk body is large and holds the per-pixel lists in
+  // registers: a second inlined copy costs registers): refill the id list from the next mask
+  // chunk when it runs dry, take up to 64 ids, test + append, walk when the list could overflow
+  // or everything has been appended
+  int w0 = -64, total = 0, i0 = 0, f0 = 0, fe = 0;
+  bool direct = false, done = false;
+#pragma unroll 1
+  for (;;) {
+#pragma unroll 1
+    while (!done && !(direct ? f0 < fe : i0 < total)) {
+      w0 += 64;
+      if (w0 >= words) { done = true; break; }
+      unsigned long long m = (w0 + t.lane < words) ? mrow[w0 + t.lane] : 0ull;
+      const int cnt = __popcll(m);
+      const int incl = wave_inclusive_scan(cnt, t.lane);
+      total = __builtin_amdgcn_readlane(incl, 63);
+      i0 = 0;
+      direct = total > FLCAP;  // a coarse tile crowded beyond the id list: test these 4096 faces directly
+      if (direct) {
+        f0 = w0 * 64; fe = min(F, (w0 + 64) * 64); total = 0;
+      } else if (total > 0) {
+        int pos = incl - cnt;
+        const int fbase = (w0 + t.lane) * 64;
+#pragma unroll 1
+        while (m != 0ull) {
+          s_fl[pos++] = fbase + (int)__ffsll((long long)m) - 1;
+          m &= m - 1ull;
+        }
+        wave_lds_sync();
+      }
     }
-    const unsigned long long bal = __ballot(pass);
-    if (t.lane == 0) L.wcnt[r & 1][t.wv] = __popcll(bal);
-    __syncthreads();
-    int off = list_n, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = L.wcnt[r & 1][i];
-      if (i < t.wv) off += c;
-      tot += c;
+    if (!done) {
+      int f;
+      if (direct) { f = (f0 + t.lane < fe) ? f0 + t.lane : -1; f0 += RT; }
+      else { f = (i0 + t.lane < total) ? s_fl[i0 + t.lane] : -1; i0 += RT; }
+      bool pass = false;
+      float4 b = make_float4(0, 0, 0, 0);
+      if (f >= 0) {
+        b = ws.box[(size_t)t.n * F + f];
+        pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
+      }
+      const unsigned long long bal = __ballot(pass);
+      if (pass) {
+        const int pos = list_n + __popcll(bal & lt);
+        const size_t o = (size_t)t.n * F + f;
+        L.box[pos] = b;
+        L.a[pos] = ws.recA[o];
+        L.b[pos] = ws.recB[o];
+        const float4 c4 = ws.recC[o];
+        L.c[pos] = make_float2(c4.x, c4.y);
+        L.fid[pos] = f;
+      }
+      list_n += __popcll(bal);
     }
-    if (pass) {
-      const int pos = off + __popcll(bal & ((1ull << t.lane) - 1ull));
-      const size_t o = (size_t)t.n * F + f;
-      L.box[pos] = b;
-      L.a[pos] = ws.recA[o];
-      L.b[pos] = ws.recB[o];
-      const float4 c4 = ws.recC[o];
-      L.c[pos] = make_float2(c4.x, c4.y);
-      L.fid[pos] = f;
-      if (WITH_VIDX) s_vidx[pos] = ws.vidx[o];
-    }
-    list_n += tot;
-    const bool last = (r == rounds - 1);
-    if (list_n > CAP - TPB || last) {
-      __syncthreads();
-      if (list_n > 0) walk(list_n);
+    if (list_n > RCAP - RT || (done && list_n > 0)) {
+      wave_lds_sync();
+      walk(list_n);
+      wave_lds_sync();
       list_n = 0;
-      if (!last) __syncthreads();
     }
+    if (done) break;
   }
 }
 
@@ -535,9 +600,10 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
 }
 
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+__global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
   __shared__ CandList L;
+  __shared__ int s_fl[FLCAP];
   const Tile t = make_tile(ws, N, H);
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
@@ -557,7 +623,7 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
     float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
-    bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
+    bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
         Hit h;
@@ -622,14 +688,14 @@ __global__ __launch_bounds__(TPB) void k_raster_fwd(RasterWs ws, int N, int F, i
     // registers.  A new face is bubbled through the array with compare-exchanges on static
     // register indices (the displaced farthest entry falls off the end), so there is no LDS or
     // memory list, no final sort and the kept set is exactly the K nearest at every moment.
-    __shared__ unsigned short s_wl[4][CAP];  // per wave: candidates whose box meets its 8x8 pixels
+    __shared__ unsigned short s_wl[RCAP];  // first stage of the edge cull
     unsigned long long key[K];
     float q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
-    bin_and_walk<false>(ws, t, F, L, nullptr, [&](int list_n) {
-      walk_wave<true>(L, t, H, list_n, blur, s_wl[t.wv], [&](const Cand& cd, bool in_box, int ord) {
+    bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
+      walk_wave<true>(L, t, H, list_n, blur, s_wl, [&](const Cand& cd, bool in_box, int ord) {
         // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list
         // cannot enter it; when that holds for every lane of the wave the face is dropped
         // before its edge distances are computed (empty slots hold ~0, so x < key[K-1] is
@@ -705,13 +771,17 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
   gbx = g * t * ex; gby = g * t * ey;
 }
 
-__global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
+__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
                                                  const float* __restrict__ grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {
   __shared__ CandList L;
-  __shared__ int4 s_vidx[CAP];
-  extern __shared__ float s_g[];  // [V][2] tile-local vertex gradient
+  __shared__ int s_fl[FLCAP];
+  // gradient accumulator per list slot: (d/dx0, d/dy0, d/dx1, d/dy1, d/dx2, d/dy2) of that face,
+  // summed over the block's pixels; flushed (global float atomics on the face's three vertices)
+  // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
+  // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
+  __shared__ float s_acc[RCAP][6];
   const Tile t = make_tile(ws, N, H);
 
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
@@ -726,13 +796,13 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
     }
   }
   const bool work = (coef != 0.0f);
-  if (!__syncthreads_or(work)) return;
+  if (__ballot(work) == 0ull) return;
 
-  for (int i = t.tid; i < 2 * V; i += TPB) s_g[i] = 0.f;
-  // (the first barrier inside bin_and_walk orders this before any accumulation)
+  for (int i = t.tid; i < RCAP * 6; i += RT) (&s_acc[0][0])[i] = 0.f;
+  wave_lds_sync();
+  float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
 
-  bin_and_walk<true>(ws, t, F, L, s_vidx, [&](int list_n) {
-    if (__ballot(work) == 0ull) return;  // nothing to do in this 8x8 block
+  bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
     walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
       bool member = work && in_box;
       if (__ballot(member) == 0ull) return;
@@ -772,22 +842,31 @@ __global__ __launch_bounds__(TPB) void k_sil_bwd(RasterWs ws, const float* __res
       g2x = row_sum_dpp(g2x); g2y = row_sum_dpp(g2y);
       // (a row without a face this iteration, or without members, sums to exact zeros)
       if ((t.lane & 15) == 15) {
-        const int4 vi = s_vidx[cd.idx];
-        if (g0x != 0.f) atomicAdd(&s_g[2 * vi.x], g0x);
-        if (g0y != 0.f) atomicAdd(&s_g[2 * vi.x + 1], g0y);
-        if (g1x != 0.f) atomicAdd(&s_g[2 * vi.y], g1x);
-        if (g1y != 0.f) atomicAdd(&s_g[2 * vi.y + 1], g1y);
-        if (g2x != 0.f) atomicAdd(&s_g[2 * vi.z], g2x);
-        if (g2y != 0.f) atomicAdd(&s_g[2 * vi.z + 1], g2y);
+        float* acc = s_acc[cd.idx];   // two groups can hold the same face in one iteration: atomics
+        if (g0x != 0.f) atomicAdd(&acc[0], g0x);
+        if (g0y != 0.f) atomicAdd(&acc[1], g0y);
+        if (g1x != 0.f) atomicAdd(&acc[2], g1x);
+        if (g1y != 0.f) atomicAdd(&acc[3], g1y);
+        if (g2x != 0.f) atomicAdd(&acc[4], g2x);
+        if (g2y != 0.f) atomicAdd(&acc[5], g2y);
       }
     });
+    wave_lds_sync();
+    for (int c = t.lane; c < list_n; c += RT) {
+      float* acc = s_acc[c];
+      const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
+      if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f) {
+        const int4 vi = ws.vidx[(size_t)t.n * F + L.fid[c]];
+        if (a0 != 0.f) atomicAdd(&gout[2 * vi.x], a0);
+        if (a1 != 0.f) atomicAdd(&gout[2 * vi.x + 1], a1);
+        if (a2 != 0.f) atomicAdd(&gout[2 * vi.y], a2);
+        if (a3 != 0.f) atomicAdd(&gout[2 * vi.y + 1], a3);
+        if (a4 != 0.f) atomicAdd(&gout[2 * vi.z], a4);
+        if (a5 != 0.f) atomicAdd(&gout[2 * vi.z + 1], a5);
+        acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f; acc[4] = 0.f; acc[5] = 0.f;
+      }
+    }
   });
-  __syncthreads();
-  float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
-  for (int i = t.tid; i < 2 * V; i += TPB) {
-    const float v = s_g[i];
-    if (v != 0.0f) atomicAdd(&gout[i], v);
-  }
 }
 
 // ------------------------------------------------------------------------------- projection
@@ -906,10 +985,15 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
                         int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
                         hipStream_t st) {
   const float margin = sqrtf(blur);
-  const int tiles = (H + TILE - 1) / TILE;
+  const int tiles = (H + RBLK - 1) / RBLK;
   const int tt = tiles * tiles;
-  const size_t lds = sizeof(float) * 3 * (size_t)V + (tt <= SETUP_LDS_TILES ? sizeof(int) * (size_t)tt : 0);
+  const int ctiles = (H + CTILE - 1) / CTILE;
+  const size_t mask_bytes = sizeof(unsigned) * 2 * (size_t)ctiles * ctiles * (((size_t)F + 63) / 64);
+  const bool lds_mask = mask_bytes <= (size_t)SETUP_LDS_MASK_BYTES;
+  const size_t lds = sizeof(float) * 3 * (size_t)V + (tt <= SETUP_LDS_TILES ? sizeof(int) * (size_t)tt : 0) +
+                     (lds_mask ? mask_bytes : 0);
   if (lds > 150 * 1024) return ACFM_E_BADARG;
+  if (!lds_mask && hipMemsetAsync(ws.cmask, 0, mask_bytes * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
   if (tt > SETUP_LDS_TILES &&
       hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * (size_t)N * tt, st) != hipSuccess)
     return ACFM_E_LAUNCH;
@@ -923,11 +1007,12 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
 
 static bool bad_dims(int N, int V, int F, int H) {
   return N <= 0 || N > 65535 || V <= 0 || F <= 0 || F > ACFM_MAX_FACES || H <= 0 || H > 4096 ||
-         (size_t)N * F > 0x7fffffffull;
+         (size_t)N * F > 0x7fffffffull ||
+         (size_t)N * ((H + RBLK - 1) / RBLK) * ((H + RBLK - 1) / RBLK) > 0x7fffffffull;
 }
 
 static unsigned tile_grid(int N, int H) {
-  const int tiles = (H + TILE - 1) / TILE;
+  const int tiles = (H + RBLK - 1) / RBLK;
   return (unsigned)((size_t)tiles * tiles * N);
 }
 
@@ -935,7 +1020,7 @@ template <int K>
 static int launch_sil_fwd(const RasterWs& ws, int N, int F, int H, float blur, float sigma,
                           const FwdOut& out, hipStream_t st) {
   ProfScope ps(ACFM_PROF_SIL_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F,
                      H, blur, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -976,6 +1061,16 @@ int acfm_prof_collect(float* ms_host, int* count_host, int n) {
   }
   g_ev_n = 0;
   return ACFM_OK;
+}
+
+// diagnostic (not in the public header): resident workgroups per CU of the raster kernels
+int acfm_debug_occupancy(int which, int dyn_lds) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<20, false, false>, RT, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<1, true, true>, RT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sil_bwd, RT, 0);
+  return e == hipSuccess ? n : -1;
 }
 
 const char* acfm_prof_name(int id) {
@@ -1061,11 +1156,10 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   }
   if (hipMemsetAsync(ws.grad_ndc, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
     return ACFM_E_LAUNCH;
-  const size_t lds = sizeof(float) * 2 * (size_t)V;
-  if (lds > 96 * 1024) return ACFM_E_BADARG;
+  const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H)), dim3(TPB), lds, st, ws, mask,
+    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H)), dim3(RT), lds, st, ws, mask,
                        reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
                        blur_radius, sigma);
   }
@@ -1094,7 +1188,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   out.vis = vis;
   out.V = V;
   ProfScope ps(ACFM_PROF_HARD_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F,
                      H, 0.f, 1e-4f, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1118,7 +1212,7 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1142,7 +1236,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
   out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
   out.atlas = verts_rgb;  // never dereferenced when vrgb is set
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(TPB), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;

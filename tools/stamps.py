@@ -17,7 +17,7 @@ cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=dev
 faces = torch.tensor(f, device=dev)[None].repeat(N, 1, 1).contiguous()
 atlas = torch.rand(N, f.shape[0], 6, 6, 3, device=dev)
 raw = ctypes.CDLL(_lib.SO_PATH)
-nb = N * 256
+nb = N * (H // 8) ** 2   # one workgroup (wave) per 8x8 block
 buf = torch.zeros(nb * 3, dtype=torch.int64, device=dev)
 def run():
     if mode == "sil": ops.sil_render(verts, faces, cams, H)
@@ -35,7 +35,7 @@ xcc = hw >> 32
 cu = (hw & 0xffffffff)
 print("blocks", nb, "kernel span %.1f us" % span, "block dur: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (
     dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
-print("sum of block durations %.0f us -> /1280 slots = %.1f us" % (dur.sum(), dur.sum() / 1280))
+print("sum of block durations %.0f us -> /3072 wave slots (3 per SIMD) = %.1f us" % (dur.sum(), dur.sum() / 3072))
 start = (t0 - t0.min()) / 100.0
 print("start time percentiles (us): p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(start, [10, 50, 90, 100])))
 for x in range(8):
@@ -44,6 +44,6 @@ for x in range(8):
         grp = sorted(set((np.nonzero(sel)[0] & 7).tolist()))
         print("xcc", x, "blocks", sel.sum(), "block%8 groups", grp,
               "last end %.1f" % ((t1[sel].max() - t0.min()) / 100.0), "sum dur %.0f" % dur[sel].sum(),
-              "idle-weighted util %.2f" % (dur[sel].sum() / (96 * (t1[sel].max() - t0[sel].min()) / 100.0)))
+              "idle-weighted util %.2f" % (dur[sel].sum() / (384 * (t1[sel].max() - t0[sel].min()) / 100.0)))
 order = np.argsort(-dur)[:8]
 print("heaviest blocks:", [(int(i), round(float(dur[i]), 1), round(float(start[i]), 1)) for i in order])
