@@ -32,7 +32,9 @@ constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
 constexpr int RCAP = 128;     // LDS candidate-list capacity of a block (walked early when it could overflow)
 constexpr int TPB = 256;      // threads per workgroup of the per-mesh kernels (setup, projection)
 constexpr unsigned long long KEY_NONE = ~0ull;
-constexpr int SETUP_LDS_TILES = 4096;  // block counters kept in LDS up to 512x512 images
+constexpr int CNT_TILE = 16;  // cost counters are kept per 16x16 pixels (the four 8x8 blocks inside share the estimate)
+constexpr int SETUP_LDS_TILES = 4096;  // counters kept in LDS up to 1024x1024 images
+constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes near this block
 constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   __shared__ float s_red[4][4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* cam = cams ? cams + 7 * (size_t)n : nullptr;
-  const int tiles_ = (H + RBLK - 1) / RBLK, tt_ = tiles_ * tiles_;
+  const int tiles_ = (H + CNT_TILE - 1) / CNT_TILE, tt_ = tiles_ * tiles_;
   const bool lds_cnt = tt_ <= SETUP_LDS_TILES;
   int* s_cnt = reinterpret_cast<int*>(s_v + 3 * V);
   if (lds_cnt)
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   __syncthreads();
   const float INF = __builtin_inff();
   float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
+  bool big = false;
   for (int f = tid; f < F; f += TPB) {
     const int64_t* fi = faces + ((size_t)n * F + f) * 3;
     int i0 = (int)fi[0], i1 = (int)fi[1], i2 = (int)fi[2];
@@ -103,9 +106,9 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
     if (!degenerate) {
-      // cost estimate for heavy-first scheduling: +1 on every 8x8 block the box may touch
+      // cost estimate for heavy-first scheduling: +1 on every 16x16 tile the box may touch
       // (pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack)
-      const int tiles = (H + RBLK - 1) / RBLK;
+      const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
       const float hf = (float)H;
       int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
       int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
@@ -118,8 +121,10 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
         for (int cy = ya / CTILE; cy <= yb / CTILE; ++cy)
           for (int cx = xa / CTILE; cx <= xb / CTILE; ++cx)
             atomicOr(&mrow[(size_t)(cy * ctiles_ + cx) * mwords + (f >> 5)], bit);
-        xa /= RBLK; ya /= RBLK; xb /= RBLK; yb /= RBLK;
-        if ((xb - xa + 1) * (yb - ya + 1) <= 256)
+        xa /= CNT_TILE; ya /= CNT_TILE; xb /= CNT_TILE; yb /= CNT_TILE;
+        if ((xb - xa + 1) * (yb - ya + 1) > 64) {
+          big = true;  // too many tiles to count one by one: every tile of the mesh gets +1 below
+        } else
           for (int ty = ya; ty <= yb; ++ty)
             for (int tx = xa; tx <= xb; ++tx) {
               if (lds_cnt) atomicAdd(&s_cnt[ty * tiles + tx], 1);
@@ -131,9 +136,11 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
   const int w = tid >> 6;
   if ((tid & 63) == 0) { s_red[w][0] = bx0; s_red[w][1] = bx1; s_red[w][2] = by0; s_red[w][3] = by1; }
-  __syncthreads();
+  const int any_big = __syncthreads_or(big) ? 1 : 0;  // (also the barrier before the copies below)
   if (lds_cnt)
-    for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i];
+    for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i] + any_big;
+  else if (any_big)
+    for (int i = tid; i < tt_; i += TPB) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], 1);
   if (lds_mask)
     for (size_t i = tid; i < mask_n; i += TPB) g_mask[i] = s_mask[i];
   if (tid == 0) {
@@ -150,11 +157,19 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
 // take 20x the average), so every XCD group visits its (mesh, block) entries in descending cost
 // class; the long blocks start first and the short ones fill in behind them.
 // Entry e of group g  <->  mesh (e / tt) * G + g, block e % tt   (G = 8 groups if N % 8 == 0, else 1).
+// The cost of a block is the face count of its 16x16 tile (k_setup); count 0 = no face box comes
+// near: the entry is flagged and the raster kernels write that block's zeros without looking at
+// the mesh at all.
 constexpr int NCLASS = 8;
 __device__ __forceinline__ int cost_class(int c) {
-  return c >= 160 ? 0 : c >= 112 ? 1 : c >= 80 ? 2 : c >= 56 ? 3 : c >= 36 ? 4 : c >= 20 ? 5 : c >= 1 ? 6 : 7;
+  return c >= 320 ? 0 : c >= 224 ? 1 : c >= 160 ? 2 : c >= 112 ? 3 : c >= 72 ? 4 : c >= 40 ? 5 : c >= 1 ? 6 : 7;
 }
-__global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
+__device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int H) {
+  const int blocks = (H + RBLK - 1) / RBLK, tiles = (H + CNT_TILE - 1) / CNT_TILE;
+  const int by = bl / blocks, bx = bl % blocks;
+  return ws.tile_cnt[((size_t)n * tiles + by * RBLK / CNT_TILE) * tiles + bx * RBLK / CNT_TILE];
+}
+__global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int H) {
   __shared__ int s_hist[NCLASS], s_base[NCLASS];
   const int G = gridDim.x, g = blockIdx.x, lane = threadIdx.x & 63;
   const int per = (N / G) * tt;
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
   for (int it = 0; it < iters; ++it) {
     const int e = it * blockDim.x + threadIdx.x;
     int cls = -1;
-    if (e < per) cls = cost_class(ws.tile_cnt[(size_t)((e / tt) * G + g) * tt + (e % tt)]);
+    if (e < per) cls = cost_class(block_cost(ws, (e / tt) * G + g, e % tt, H));
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) {
       const unsigned long long m = __ballot(cls == c);
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
   for (int it = 0; it < iters; ++it) {
     const int e = it * blockDim.x + threadIdx.x;
     int cls = -1;
-    if (e < per) cls = cost_class(ws.tile_cnt[(size_t)((e / tt) * G + g) * tt + (e % tt)]);
+    if (e < per) cls = cost_class(block_cost(ws, (e / tt) * G + g, e % tt, H));
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) {
       const unsigned long long m = __ballot(cls == c);
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
       int base = 0;
       if (lane == leader) base = atomicAdd(&s_base[c], __popcll(m));
       base = __shfl(base, leader, 64);
-      if (cls == c) ord[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      if (cls == c) ord[base + __popcll(m & ((1ull << lane) - 1ull))] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0);
     }
   }
 }
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt) {
 // ------------------------------------------------------------------------------- tile skeleton
 struct Tile {
   int n, tid, wv, lane, yi, xi;
-  bool valid;
+  bool valid, empty;
   float xf, yf;
   size_t pix;
   float t_xmin, t_xmax, t_ymin, t_ymax;
@@ -218,11 +233,15 @@ __device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
   int n, tl;
   if ((N & 7) == 0) {
     const unsigned g = b & 7u, j = b >> 3;
-    const int e = ws.order[(size_t)g * ((N >> 3) * tt) + j];
+    const int eo = ws.order[(size_t)g * ((N >> 3) * tt) + j];
+    const int e = eo & ~ENTRY_EMPTY;
+    t.empty = (eo & ENTRY_EMPTY) != 0;
     n = (e / tt) * 8 + (int)g;
     tl = e % tt;
   } else {
-    const int e = ws.order[b];
+    const int eo = ws.order[b];
+    const int e = eo & ~ENTRY_EMPTY;
+    t.empty = (eo & ENTRY_EMPTY) != 0;
     n = e / tt;
     tl = e % tt;
   }
@@ -421,6 +440,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
 template <class Walk>
 __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, CandList& L,
                                              int* s_fl /* [FLCAP] */, Walk&& walk) {
+  if (t.empty) return;  // flagged by k_order: no face box near this block
   const float4 mb = ws.mbox[t.n];
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
   const unsigned long long lt = (1ull << t.lane) - 1ull;
@@ -788,6 +808,7 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
   unsigned long long kthkey = KEY_NONE;
+  if (t.empty) return;  // the forward wrote mask = 0 here
   if (t.valid) {
     const float m = mask[t.pix];
     if (m != 0.0f) {
@@ -985,8 +1006,9 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
                         int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
                         hipStream_t st) {
   const float margin = sqrtf(blur);
-  const int tiles = (H + RBLK - 1) / RBLK;
-  const int tt = tiles * tiles;
+  const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
+  const int tt = tiles * tiles;                 // cost counters
+  const int blocks = (H + RBLK - 1) / RBLK;
   const int ctiles = (H + CTILE - 1) / CTILE;
   const size_t mask_bytes = sizeof(unsigned) * 2 * (size_t)ctiles * ctiles * (((size_t)F + 63) / 64);
   const bool lds_mask = mask_bytes <= (size_t)SETUP_LDS_MASK_BYTES;
@@ -1000,7 +1022,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws);
-  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, tt);
+  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
