@@ -23,6 +23,9 @@
 
 namespace acfm {
 
+// stream-ordered zero fill by a kernel (the library issues no hipMemsetAsync: see acfm_raster.hip)
+int zero_async(void* p, size_t nbytes, hipStream_t st);
+
 // per-kernel hipEvent bracketing (acfm_prof_* in include/acfm_hip.h); state lives in acfm_raster.hip
 void prof_begin(int id, hipStream_t st);
 void prof_end(hipStream_t st);
@@ -40,7 +43,7 @@ struct RasterWs {
   float4* recC;    // [N,F] (z2, area, -, -)
   float4* box;     // [N,F] (xmin,xmax,ymin,ymax), blur margin included; degenerate = (inf,-inf,inf,-inf)
   int4* vidx;      // [N,F] (i0,i1,i2,-)
-  float4* mbox;    // [N]   union of the face boxes
+  float4* mbox;    // [N,4] union of the face boxes of each of the 4 face slices of k_setup
   float* grad_ndc; // [N,V,2]
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
@@ -60,7 +63,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   w.recC = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
   w.box = (float4*)(p + o);     o += align256(sizeof(float4) * (size_t)N * F);
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
-  w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N);
+  w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * 4 * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
   const size_t tt = (size_t)((H + 7) / 8) * ((H + 7) / 8);  // 8x8-pixel blocks (RBLK)
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);

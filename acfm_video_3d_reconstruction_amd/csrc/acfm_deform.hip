@@ -157,7 +157,7 @@ int acfm_deform_apply_backward(const float* P, const float* delta, const float* 
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_DEFORM_BWD, st);
   if (grad_delta) {
-    if (hipMemsetAsync(grad_delta, 0, sizeof(float) * 3 * (size_t)N * Kh, st) != hipSuccess) return ACFM_E_LAUNCH;
+    if (zero_async(grad_delta, sizeof(float) * 3 * (size_t)N * Kh, st) != ACFM_OK) return ACFM_E_LAUNCH;
     hipLaunchKernelGGL(k_deform_grad_delta, dim3((Kh + 15) / 16, (3 * N + 63) / 64, (V + VCHUNK - 1) / VCHUNK),
                        dim3(256), 0, st, P, grad_verts, N, V, Kh, grad_delta);
   }
@@ -165,7 +165,7 @@ int acfm_deform_apply_backward(const float* P, const float* delta, const float* 
     hipLaunchKernelGGL(k_deform_grad_P, dim3((V + 15) / 16, (Kh + 63) / 64), dim3(256), 0, st, grad_verts,
                        delta, N, V, Kh, grad_P);
   if (grad_mean) {
-    if (hipMemsetAsync(grad_mean, 0, sizeof(float) * 3 * (size_t)V, st) != hipSuccess) return ACFM_E_LAUNCH;
+    if (zero_async(grad_mean, sizeof(float) * 3 * (size_t)V, st) != ACFM_OK) return ACFM_E_LAUNCH;
     hipLaunchKernelGGL(k_deform_grad_mean, dim3((3 * V + 255) / 256, (N + MEAN_FRAMES - 1) / MEAN_FRAMES),
                        dim3(256), 0, st, grad_verts, N, 3 * V, grad_mean);
   }

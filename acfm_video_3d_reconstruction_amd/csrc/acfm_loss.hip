@@ -193,7 +193,7 @@ int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N
                      void* stream) {
   if (!mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * 4 * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(out, sizeof(float) * 4 * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   const int chunks = (HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
   ProfScope ps(ACFM_PROF_MASK_LOSS, st);
   hipLaunchKernelGGL(k_mask_losses, dim3(chunks, N), dim3(LTPB), 0, st, mask, gt, edt, HW, out);
@@ -216,7 +216,7 @@ int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, i
                  void* stream) {
   if (!tex || !img || !mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(out, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_TEX_MSE, st);
   hipLaunchKernelGGL(k_tex_mse, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st, tex,
                      img, mask, HW, out);
@@ -241,7 +241,7 @@ int acfm_visible_vertices(const int64_t* pix_to_face, const int64_t* faces, int 
   if (!pix_to_face || !faces || !vis || N <= 0 || N > 65535 || V <= 0 || F <= 0 || HW <= 0 || K <= 0)
     return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(vis, (size_t)N * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_VISIBLE, st);
   hipLaunchKernelGGL(k_visible, dim3((HW + 255) / 256, N), dim3(256), 0, st, pix_to_face, faces, V, F,
                      HW, K, vis);
@@ -256,7 +256,7 @@ int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, i
   const size_t lds = sizeof(float) * 2 * (size_t)V;
   if (lds > 150 * 1024) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(loss, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(loss, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_BDS, st);
   hipLaunchKernelGGL(k_bds_loss, dim3((P + LTPB - 1) / LTPB, N), dim3(LTPB), lds, st, verts_xy, bds, vis,
                      V, P, loss, argmin);
@@ -271,7 +271,7 @@ int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_
       P <= 0)
     return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_verts_xy, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
+  if (zero_async(grad_verts_xy, sizeof(float) * 2 * (size_t)N * V, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_BDS_BWD, st);
   hipLaunchKernelGGL(k_bds_loss_bwd, dim3((P + 255) / 256, N), dim3(256), 0, st, verts_xy, bds, argmin,

@@ -224,7 +224,7 @@ extern "C" {
 int acfm_cot_laplacian(const float* verts, const int64_t* faces, int V, int F, float* L, void* stream) {
   if (!verts || !faces || !L || V <= 0 || F <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(L, 0, sizeof(float) * (size_t)V * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(L, sizeof(float) * (size_t)V * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_cot_laplacian, dim3(nblk(F, 256)), dim3(256), 0, st, verts, faces, V, F, L);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -243,8 +243,8 @@ int acfm_laplacian_smoothing(const float* verts, const int64_t* conn, const floa
   hipStream_t st = (hipStream_t)stream;
   float* Wv = state; float* rowsum = state + 3 * (size_t)P; float* glv = state + 4 * (size_t)P;
   float* wface = state + 7 * (size_t)P;
-  if (hipMemsetAsync(state, 0, sizeof(float) * 4 * (size_t)P, st) != hipSuccess) return ACFM_E_LAUNCH;
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(state, sizeof(float) * 4 * (size_t)P, st) != ACFM_OK) return ACFM_E_LAUNCH;
+  if (zero_async(loss, sizeof(float), st) != ACFM_OK) return ACFM_E_LAUNCH;
   if (method == 0)
     hipLaunchKernelGGL(k_lap_accum_faces, dim3(nblk(F, 256)), dim3(256), 0, st, verts, conn, P, F, Wv, rowsum, wface);
   else
@@ -277,7 +277,7 @@ int acfm_edge_rigidity(const float* verts, const int64_t* edges, const float* ve
                        int E, float* loss, void* stream) {
   if (!verts || !edges || !verts_t || !edges_t || !loss || E <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(loss, sizeof(float), st) != ACFM_OK) return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_rigid, dim3(nblk(E, MTPB)), dim3(MTPB), 0, st, verts, edges, verts_t, edges_t, E, loss);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -288,8 +288,8 @@ int acfm_edge_rigidity_backward(const float* verts, const int64_t* edges, const 
                                 float* grad_verts_t, void* stream) {
   if (!verts || !edges || !verts_t || !edges_t || !grad_loss || E <= 0 || P <= 0 || Pt <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (grad_verts && hipMemsetAsync(grad_verts, 0, sizeof(float) * 3 * (size_t)P, st) != hipSuccess) return ACFM_E_LAUNCH;
-  if (grad_verts_t && hipMemsetAsync(grad_verts_t, 0, sizeof(float) * 3 * (size_t)Pt, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (grad_verts && zero_async(grad_verts, sizeof(float) * 3 * (size_t)P, st) != ACFM_OK) return ACFM_E_LAUNCH;
+  if (grad_verts_t && zero_async(grad_verts_t, sizeof(float) * 3 * (size_t)Pt, st) != ACFM_OK) return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_rigid_bwd, dim3(nblk(E, 256)), dim3(256), 0, st, verts, edges, verts_t, edges_t, E, grad_loss,
                      grad_verts, grad_verts_t);
   ACFM_CHECK_LAUNCH();

@@ -138,7 +138,7 @@ int acfm_edt(const float* mask, int N, int H, int W, int divisor, float* out, vo
   hipStream_t st = (hipStream_t)stream;
   int* g = (int*)wsp;
   int* any_fg = (int*)((char*)wsp + align256(sizeof(int) * (size_t)N * H * W));
-  if (hipMemsetAsync(any_fg, 0, sizeof(int) * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (zero_async(any_fg, sizeof(int) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_edt_cols, dim3((W + PTPB - 1) / PTPB, N), dim3(PTPB), 0, st, mask, H, W, g, any_fg);
   hipLaunchKernelGGL(k_edt_rows, dim3(H, N), dim3(PTPB), sizeof(int) * (size_t)W, st, (const int*)g,
                      (const int*)any_fg, H, W, divisor, out);

@@ -32,7 +32,7 @@ constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
 constexpr int RCAP = 128;     // LDS candidate-list capacity of a block (walked early when it could overflow)
 constexpr int TPB = 256;      // threads per workgroup of the per-mesh kernels (setup, projection)
 constexpr unsigned long long KEY_NONE = ~0ull;
-constexpr int CNT_TILE = 16;  // cost counters are kept per 16x16 pixels (the four 8x8 blocks inside share the estimate)
+constexpr int CNT_TILE = 8;   // cost counters per 8x8 pixels (= per raster block)
 constexpr int SETUP_LDS_TILES = 4096;  // counters kept in LDS up to 1024x1024 images
 constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes near this block
 constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
@@ -42,27 +42,40 @@ constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coar
 // ------------------------------------------------------------------------------- setup
 // mode 0: verts are world coordinates -> project with cams, flip y   (nmr.py:145-149)
 // mode 1: verts are already projected, no y flip                     (nmr.py:224-238)
+// Grid (N, SETUP_SLICES): every workgroup projects the mesh's V vertices into LDS (cheap, and it
+// keeps the slices independent) and handles one slice of the faces; slice boundaries are multiples
+// of 64 faces, so each slice owns whole words of the coarse masks and builds them in LDS without
+// talking to the others.  Tile counters are summed into zeroed memory with global atomics, the
+// mesh box is left as one box per slice (the raster kernels take the union of the four).
+constexpr int SETUP_SLICES = 4;
+__host__ __device__ __forceinline__ int setup_slice_faces(int F) {
+  return ((F + SETUP_SLICES - 1) / SETUP_SLICES + 63) / 64 * 64;
+}
+
 __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
                                                const float* __restrict__ cams, int V, int F, int H,
                                                float offset_z, int mode, float margin, RasterWs ws) {
-  extern __shared__ float s_v[];  // [V][3], then (if they fit) [blocks^2] int counters and the coarse masks
+  extern __shared__ float s_v[];  // [V][3], then [tiles^2] int counters and this slice's mask words (if they fit)
   __shared__ float s_red[4][4];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
   const float* cam = cams ? cams + 7 * (size_t)n : nullptr;
   const int tiles_ = (H + CNT_TILE - 1) / CNT_TILE, tt_ = tiles_ * tiles_;
   const bool lds_cnt = tt_ <= SETUP_LDS_TILES;
   int* s_cnt = reinterpret_cast<int*>(s_v + 3 * V);
   if (lds_cnt)
     for (int i = tid; i < tt_; i += TPB) s_cnt[i] = 0;
+  const int q = setup_slice_faces(F);
+  const int f_lo = slice * q, f_hi = min(F, f_lo + q);
   // coarse face masks: bit f of row (cty, ctx) <=> the box of face f may touch that 32x32 tile
   const int ctiles_ = (H + CTILE - 1) / CTILE, mwords = 2 * ((F + 63) / 64);  // u32 words per row
-  const size_t mask_n = (size_t)ctiles_ * ctiles_ * mwords;
-  const bool lds_mask = mask_n * sizeof(unsigned) <= (size_t)SETUP_LDS_MASK_BYTES;
-  unsigned* g_mask = ws.cmask + (size_t)n * mask_n;                    // zeroed by the host if !lds_mask
+  const int rows = ctiles_ * ctiles_;
+  const int w_lo = f_lo >> 5, w_n = max(0, min(mwords, (f_lo + q) >> 5) - w_lo);  // this slice's words of a row
+  const bool lds_mask = (size_t)rows * w_n * sizeof(unsigned) <= (size_t)SETUP_LDS_MASK_BYTES;
+  unsigned* g_mask = ws.cmask + (size_t)n * rows * mwords;              // zeroed by the host if !lds_mask
   unsigned* s_mask = reinterpret_cast<unsigned*>(s_cnt + (lds_cnt ? tt_ : 0));
   if (lds_mask)
-    for (size_t i = tid; i < mask_n; i += TPB) s_mask[i] = 0u;
+    for (int i = tid; i < rows * w_n; i += TPB) s_mask[i] = 0u;
   for (int v = tid; v < V; v += TPB) {
     const float* x = verts + ((size_t)n * V + v) * 3;
     float px, py, pz;
@@ -75,14 +88,16 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     px = -px;               // view R = diag(-1, 1, 1)
     pz = pz + ACFM_EYE_Z;   // view T = (0, 0, 2.732)
     s_v[3 * v + 0] = px; s_v[3 * v + 1] = py; s_v[3 * v + 2] = pz;
-    float* o = ws.ndc + ((size_t)n * V + v) * 3;
-    o[0] = px; o[1] = py; o[2] = pz;
+    if (slice == 0) {
+      float* o = ws.ndc + ((size_t)n * V + v) * 3;
+      o[0] = px; o[1] = py; o[2] = pz;
+    }
   }
   __syncthreads();
   const float INF = __builtin_inff();
   float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
   bool big = false;
-  for (int f = tid; f < F; f += TPB) {
+  for (int f = f_lo + tid; f < f_hi; f += TPB) {
     const int64_t* fi = faces + ((size_t)n * F + f) * 3;
     int i0 = (int)fi[0], i1 = (int)fi[1], i2 = (int)fi[2];
     i0 = min(max(i0, 0), V - 1); i1 = min(max(i1, 0), V - 1); i2 = min(max(i2, 0), V - 1);
@@ -106,9 +121,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
     if (!degenerate) {
-      // cost estimate for heavy-first scheduling: +1 on every 16x16 tile the box may touch
-      // (pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack)
-      const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
+      // pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack
       const float hf = (float)H;
       int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
       int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
@@ -116,19 +129,22 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
       int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
       if (xb >= 0 && yb >= 0 && xa < H && ya < H) {
         xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
-        unsigned* mrow = lds_mask ? s_mask : g_mask;
         const unsigned bit = 1u << (f & 31);
         for (int cy = ya / CTILE; cy <= yb / CTILE; ++cy)
-          for (int cx = xa / CTILE; cx <= xb / CTILE; ++cx)
-            atomicOr(&mrow[(size_t)(cy * ctiles_ + cx) * mwords + (f >> 5)], bit);
+          for (int cx = xa / CTILE; cx <= xb / CTILE; ++cx) {
+            const int row = cy * ctiles_ + cx;
+            if (lds_mask) atomicOr(&s_mask[row * w_n + ((f >> 5) - w_lo)], bit);
+            else atomicOr(&g_mask[(size_t)row * mwords + (f >> 5)], bit);
+          }
+        // cost estimate for heavy-first scheduling: +1 on every 16x16 tile the box may touch
         xa /= CNT_TILE; ya /= CNT_TILE; xb /= CNT_TILE; yb /= CNT_TILE;
-        if ((xb - xa + 1) * (yb - ya + 1) > 64) {
+        if ((xb - xa + 1) * (yb - ya + 1) > 256) {
           big = true;  // too many tiles to count one by one: every tile of the mesh gets +1 below
         } else
           for (int ty = ya; ty <= yb; ++ty)
             for (int tx = xa; tx <= xb; ++tx) {
-              if (lds_cnt) atomicAdd(&s_cnt[ty * tiles + tx], 1);
-              else atomicAdd(&ws.tile_cnt[((size_t)n * tiles + ty) * tiles + tx], 1);
+              if (lds_cnt) atomicAdd(&s_cnt[ty * tiles_ + tx], 1);
+              else atomicAdd(&ws.tile_cnt[((size_t)n * tiles_ + ty) * tiles_ + tx], 1);
             }
       }
     }
@@ -137,19 +153,37 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   const int w = tid >> 6;
   if ((tid & 63) == 0) { s_red[w][0] = bx0; s_red[w][1] = bx1; s_red[w][2] = by0; s_red[w][3] = by1; }
   const int any_big = __syncthreads_or(big) ? 1 : 0;  // (also the barrier before the copies below)
-  if (lds_cnt)
-    for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i] + any_big;
-  else if (any_big)
-    for (int i = tid; i < tt_; i += TPB) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], 1);
+  for (int i = tid; i < tt_; i += TPB) {              // ws.tile_cnt was zeroed by the host
+    const int c = (lds_cnt ? s_cnt[i] : 0) + any_big;
+    if (c != 0) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], c);
+  }
   if (lds_mask)
-    for (size_t i = tid; i < mask_n; i += TPB) g_mask[i] = s_mask[i];
+    for (int i = tid; i < rows * w_n; i += TPB)
+      g_mask[(size_t)(i / w_n) * mwords + w_lo + (i % w_n)] = s_mask[i];
   if (tid == 0) {
     for (int i = 1; i < 4; ++i) {
       bx0 = fminf(bx0, s_red[i][0]); bx1 = fmaxf(bx1, s_red[i][1]);
       by0 = fminf(by0, s_red[i][2]); by1 = fmaxf(by1, s_red[i][3]);
     }
-    ws.mbox[n] = make_float4(bx0, bx1, by0, by1);
+    ws.mbox[(size_t)n * SETUP_SLICES + slice] = make_float4(bx0, bx1, by0, by1);
   }
+}
+
+// Zero-fill by a kernel instead of hipMemsetAsync: a memset node in front of k_setup came out
+// wrong when the call was captured into a hipGraph and replayed (tests/test_gpu_render.py::
+// test_hip_graph_capture_and_replay); kernel nodes replay reliably, so the library uses no memsets.
+__global__ void k_zero_bytes(unsigned char* __restrict__ p, size_t nbytes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nw = nbytes >> 2;
+  if (i < nw) reinterpret_cast<unsigned*>(p)[i] = 0u;
+  if (i < (nbytes & 3)) p[(nw << 2) + i] = 0;
+}
+int zero_async(void* p, size_t nbytes, hipStream_t st) {
+  if (nbytes == 0) return ACFM_OK;
+  if (((uintptr_t)p & 3) != 0) return ACFM_E_BADARG;
+  const size_t n = (nbytes >> 2) > 4 ? (nbytes >> 2) : 4;
+  hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned char*)p, nbytes);
+  return hipGetLastError() == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
 }
 
 // ------------------------------------------------------------------------------- scheduling
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
 // the mesh at all.
 constexpr int NCLASS = 8;
 __device__ __forceinline__ int cost_class(int c) {
-  return c >= 320 ? 0 : c >= 224 ? 1 : c >= 160 ? 2 : c >= 112 ? 3 : c >= 72 ? 4 : c >= 40 ? 5 : c >= 1 ? 6 : 7;
+  return c >= 160 ? 0 : c >= 112 ? 1 : c >= 80 ? 2 : c >= 56 ? 3 : c >= 36 ? 4 : c >= 20 ? 5 : c >= 1 ? 6 : 7;
 }
 __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int H) {
   const int blocks = (H + RBLK - 1) / RBLK, tiles = (H + CNT_TILE - 1) / CNT_TILE;
@@ -441,7 +475,12 @@ template <class Walk>
 __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, CandList& L,
                                              int* s_fl /* [FLCAP] */, Walk&& walk) {
   if (t.empty) return;  // flagged by k_order: no face box near this block
-  const float4 mb = ws.mbox[t.n];
+  float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
+#pragma unroll
+  for (int i = 1; i < SETUP_SLICES; ++i) {
+    const float4 m2 = ws.mbox[(size_t)t.n * SETUP_SLICES + i];
+    mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
+  }
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
@@ -1010,17 +1049,17 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   const int tt = tiles * tiles;                 // cost counters
   const int blocks = (H + RBLK - 1) / RBLK;
   const int ctiles = (H + CTILE - 1) / CTILE;
-  const size_t mask_bytes = sizeof(unsigned) * 2 * (size_t)ctiles * ctiles * (((size_t)F + 63) / 64);
-  const bool lds_mask = mask_bytes <= (size_t)SETUP_LDS_MASK_BYTES;
+  const size_t mwords = 2 * (((size_t)F + 63) / 64);
+  const size_t slice_words = (size_t)setup_slice_faces(F) / 32;
+  const size_t slice_mask_bytes = sizeof(unsigned) * (size_t)ctiles * ctiles * (slice_words < mwords ? slice_words : mwords);
+  const bool lds_mask = slice_mask_bytes <= (size_t)SETUP_LDS_MASK_BYTES;
   const size_t lds = sizeof(float) * 3 * (size_t)V + (tt <= SETUP_LDS_TILES ? sizeof(int) * (size_t)tt : 0) +
-                     (lds_mask ? mask_bytes : 0);
+                     (lds_mask ? slice_mask_bytes : 0);
   if (lds > 150 * 1024) return ACFM_E_BADARG;
-  if (!lds_mask && hipMemsetAsync(ws.cmask, 0, mask_bytes * (size_t)N, st) != hipSuccess) return ACFM_E_LAUNCH;
-  if (tt > SETUP_LDS_TILES &&
-      hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * (size_t)N * tt, st) != hipSuccess)
-    return ACFM_E_LAUNCH;
+  if (!lds_mask && zero_async(ws.cmask, sizeof(unsigned) * (size_t)N * ctiles * ctiles * mwords, st)) return ACFM_E_LAUNCH;
+  if (zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
-  hipLaunchKernelGGL(k_setup, dim3(N), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
+  hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws);
   hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H);
   ACFM_CHECK_LAUNCH();
@@ -1142,7 +1181,7 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
   if (rc) return rc;
-  if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (vis && zero_async(vis, (size_t)N * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.dbg = g_dbg;
   out.mask = mask;
@@ -1176,7 +1215,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
     int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
     if (rc) return rc;
   }
-  if (hipMemsetAsync(ws.grad_ndc, 0, sizeof(float) * 2 * (size_t)N * V, st) != hipSuccess)
+  if (zero_async(ws.grad_ndc, sizeof(float) * 2 * (size_t)N * V, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   const size_t lds = 0;
   {
@@ -1203,7 +1242,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, st);
   if (rc) return rc;
-  if (vis && hipMemsetAsync(vis, 0, (size_t)N * V, st) != hipSuccess) return ACFM_E_LAUNCH;
+  if (vis && zero_async(vis, (size_t)N * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
@@ -1269,7 +1308,7 @@ int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, i
   if (!grad_imgs || !texel_idx || !grad_atlas || N <= 0 || F <= 0 || H <= 0 || R <= 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * H * H;
-  if (hipMemsetAsync(grad_atlas, 0, sizeof(float) * 3 * (size_t)N * F * R * R, st) != hipSuccess)
+  if (zero_async(grad_atlas, sizeof(float) * 3 * (size_t)N * F * R * R, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_TEX_BWD, st);
   hipLaunchKernelGGL(k_tex_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grad_imgs,

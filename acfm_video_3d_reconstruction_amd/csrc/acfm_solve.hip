@@ -440,8 +440,7 @@ int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P,
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_SOLVE, st);
   // the identity rows start as zero (k_solve_softmax writes their diagonal)
-  if (hipMemsetAsync(s.W + (size_t)(s.n_pad + NB) * s.ld, 0, sizeof(double) * (size_t)s.n_pad * s.ld, st) !=
-      hipSuccess)
+  if (zero_async(s.W + (size_t)(s.n_pad + NB) * s.ld, sizeof(double) * (size_t)s.n_pad * s.ld, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_solve_softmax, dim3(KHP), dim3(256), 0, st, lbs, s, Kh);
   hipLaunchKernelGGL(k_solve_gram_rows, dim3(s.n_pad), dim3(256), 0, st, L, s, Kh);
