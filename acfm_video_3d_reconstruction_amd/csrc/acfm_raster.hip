@@ -473,7 +473,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
 
 template <class Walk>
 __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, CandList& L,
-                                             int* s_fl /* [FLCAP] */, Walk&& walk) {
+                                             int* s_fl /* [FLCAP] */, float box_shrink, Walk&& walk) {
   if (t.empty) return;  // flagged by k_order: no face box near this block
   float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
 #pragma unroll
@@ -527,6 +527,9 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
       float4 b = make_float4(0, 0, 0, 0);
       if (f >= 0) {
         b = ws.box[(size_t)t.n * F + f];
+        // a workspace shared with a render of larger blur: tighten the (margin-expanded) box; a
+        // degenerate face's (inf, -inf, inf, -inf) stays what it is
+        b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
         pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
       }
       const unsigned long long bal = __ballot(pass);
@@ -630,6 +633,7 @@ struct FwdOut {
   int32_t* tidx;             // [N,H,H]
   int R;
   float gamma;
+  float box_shrink;          // > 0: the workspace was set up with a larger blur margin; boxes are tightened by this much
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
     float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
-    bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
+    bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
         Hit h;
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
-    bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
+    bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<true>(L, t, H, list_n, blur, s_wl, [&](const Cand& cd, bool in_box, int ord) {
         // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list
         // cannot enter it; when that holds for every lane of the wave the face is dropped
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
   wave_lds_sync();
   float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
 
-  bin_and_walk(ws, t, F, H, L, s_fl, [&](int list_n) {
+  bin_and_walk(ws, t, F, H, L, s_fl, 0.f, [&](int list_n) {
     walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
       bool member = work && in_box;
       if (__ballot(member) == 0ull) return;
@@ -1258,7 +1262,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
                      const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
                      float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
-                     void* wsp, size_t ws_bytes, void* stream) {
+                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, void* stream) {
   if (!verts_world || !faces || !cams || !atlas || !imgs || !sil || !pix_to_face || !texel_idx || !wsp)
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
@@ -1266,12 +1270,16 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
-  if (rc) return rc;
+  if (ws_ready && !(ws_blur >= 0.f)) return ACFM_E_BADARG;
+  if (!ws_ready) {
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
+    if (rc) return rc;
+  }
   FwdOut out = {};
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
+  out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
   hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
@@ -1282,18 +1290,22 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
 int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
                               const float* verts_rgb, int N, int V, int F, int H, float sigma, float gamma,
                               float offset_z, float* imgs, float* sil, int64_t* pix_to_face, void* wsp,
-                              size_t ws_bytes, void* stream) {
+                              size_t ws_bytes, int ws_ready, float ws_blur, void* stream) {
   if (!verts_world || !faces || !cams || !verts_rgb || !imgs || !sil || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes + sizeof(int32_t) * (size_t)N * H * H > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
-  if (rc) return rc;
+  if (ws_ready && !(ws_blur >= 0.f)) return ACFM_E_BADARG;
+  if (!ws_ready) {
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
+    if (rc) return rc;
+  }
   FwdOut out = {};
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.vrgb = verts_rgb; out.V = V;
+  out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
   out.atlas = verts_rgb;  // never dereferenced when vrgb is set
   ProfScope ps(ACFM_PROF_TEX_FWD, st);

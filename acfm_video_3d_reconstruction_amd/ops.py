@@ -17,20 +17,55 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+_FACES = {}   # (storage ptr, offset, strides, version, shape, N) -> (source kept alive, contiguous int64 [N,F,3])
+
+
 def expand_faces(faces, N):
-    """faces [F,3] / [1,F,3] / [N,F,3] -> contiguous int64 [N,F,3] on the same device."""
+    """faces [F,3] / [1,F,3] / [N,F,3] -> contiguous int64 [N,F,3] on the same device.  The
+    reference passes one face list broadcast over the batch (`faces[None].expand(N, -1, -1)`) to
+    every render call; its materialised copy is memoised on the source tensor (storage, version)."""
     if faces.dim() == 2:
         faces = faces[None]
     if faces.shape[0] != N:
         if faces.shape[0] != 1:
             raise ValueError("faces batch %d does not match %d meshes" % (faces.shape[0], N))
         faces = faces.expand(N, -1, -1)
-    return faces.to(torch.int64).contiguous()
+    if faces.dtype == torch.int64 and faces.is_contiguous():
+        return faces
+    key = (faces.data_ptr(), faces.storage_offset(), faces.stride(), faces._version, tuple(faces.shape),
+           str(faces.dtype), str(faces.device))
+    hit = _FACES.get(key)
+    if hit is None:
+        if len(_FACES) > 8:
+            _FACES.clear()
+        hit = _FACES[key] = (faces, faces.to(torch.int64).contiguous())
+    return hit[1]
 
 
 def _workspace(N, V, F, H, device):
     nbytes = _lib.lib().acfm_raster_workspace_bytes(N, V, F, H)
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+# The face setup (projection, face records, coarse masks, schedule) of the last silhouette render
+# per device.  The reference renders the texture of the same prediction right after its silhouette
+# (multiframe/main.py:616-636): when verts / cams / faces are the same storage at the same version,
+# the texture render takes the workspace over instead of setting up again (acfm_tex_forward,
+# ws_ready).  The entry keeps its tensors alive, so an address cannot be recycled under it.
+_SETUP = {}
+
+
+def _setup_key(v, c, f, H, offset_z):
+    return (v.data_ptr(), v._version, tuple(v.shape), c.data_ptr(), c._version, f.data_ptr(), f._version,
+            tuple(f.shape), int(H), float(offset_z))
+
+
+def _shared_setup(v, c, f, H, offset_z):
+    """-> (ws, nbytes, blur) of a silhouette render of exactly these inputs, or None."""
+    ent = _SETUP.get(v.device)
+    if ent is not None and ent[0] == _setup_key(v, c, f, H, offset_z):
+        return ent[1], ent[2], ent[3]
+    return None
 
 
 # ------------------------------------------------------------------------------ projection
@@ -176,6 +211,7 @@ class _SilRender(torch.autograd.Function):
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
                 float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
                 _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_sil_forward")
+        _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f))
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
         ctx.ws = (ws, nb)  # face records + tile schedule: reused by backward (no second setup)
@@ -251,12 +287,14 @@ class _TexRender(torch.autograd.Function):
         sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
         p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
         tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
-        ws, nb = _workspace(N, V, F, H, v.device)
+        shared = _shared_setup(v, c, f, H, offset_z)
+        ws, nb, ws_blur = shared if shared is not None else (*_workspace(N, V, F, H, v.device), 0.0)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
                 float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
-                _lib.ptr(tidx), _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_tex_forward")
+                _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur),
+                _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R)
         ctx.mark_non_differentiable(sil, p2f)
@@ -303,7 +341,7 @@ def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gam
     with torch.cuda.device(v.device):
         _lib.check(_lib.lib().acfm_vertex_color_forward(
             _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(col), N, V, F, H, float(sigma), float(gamma),
-            float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f), _lib.ptr(ws), nb,
+            float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f), _lib.ptr(ws), nb, 0, 0.0,
             _lib.cur_stream(v.device)), "acfm_vertex_color_forward")
     return imgs, sil, p2f
 
