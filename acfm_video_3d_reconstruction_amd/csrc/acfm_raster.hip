@@ -178,9 +178,26 @@ __global__ void k_zero_bytes(unsigned char* __restrict__ p, size_t nbytes) {
   if (i < nw) reinterpret_cast<unsigned*>(p)[i] = 0u;
   if (i < (nbytes & 3)) p[(nw << 2) + i] = 0;
 }
+// large 16-byte-aligned buffers (atlas gradients, the solver's identity rows): 16-byte stores, 4 per thread
+__global__ __launch_bounds__(256) void k_zero_vec(uint4* __restrict__ p, size_t n16) {
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + 256 * (size_t)k;
+    if (i < n16) p[i] = z;
+  }
+}
 int zero_async(void* p, size_t nbytes, hipStream_t st) {
   if (nbytes == 0) return ACFM_OK;
   if (((uintptr_t)p & 3) != 0) return ACFM_E_BADARG;
+  if (nbytes >= (1u << 16) && ((uintptr_t)p & 15) == 0) {
+    const size_t n16 = nbytes >> 4;
+    hipLaunchKernelGGL(k_zero_vec, dim3((unsigned)((n16 + 1023) / 1024)), dim3(256), 0, st, (uint4*)p, n16);
+    p = (unsigned char*)p + (n16 << 4);
+    nbytes &= 15;
+    if (nbytes == 0) return hipGetLastError() == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
+  }
   const size_t n = (nbytes >> 2) > 4 ? (nbytes >> 2) : 4;
   hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned char*)p, nbytes);
   return hipGetLastError() == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
