@@ -679,11 +679,18 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
   }
 }
 
+struct FwdLds {
+  CandList L;
+  int fl[FLCAP];
+  unsigned short wl[RCAP];
+};
+
 template <int K, bool CLIP, bool TEX>
 __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
-  __shared__ CandList L;
-  __shared__ int s_fl[FLCAP];
+  __shared__ __attribute__((aligned(16))) FwdLds S;
+  CandList& L = S.L;
+  int* s_fl = S.fl;
   const Tile t = make_tile(ws, N, H);
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
     // registers.  A new face is bubbled through the array with compare-exchanges on static
     // register indices (the displaced farthest entry falls off the end), so there is no LDS or
     // memory list, no final sort and the kept set is exactly the K nearest at every moment.
-    __shared__ unsigned short s_wl[RCAP];  // first stage of the edge cull
+    unsigned short* s_wl = S.wl;  // first stage of the edge cull
     unsigned long long key[K];
     float q[K];
 #pragma unroll
@@ -794,26 +801,55 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
       });
       seen += list_n;
     });
-    if (!t.valid) return;
-    float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
+    if (t.valid) {
+      float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
 #pragma unroll
-    for (int k = 0; k < K; ++k) alpha = alpha * q[k];
-    out.mask[t.pix] = 1.0f - alpha;
-    if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
-    if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
-    if (out.kout == 1) {
+      for (int k = 0; k < K; ++k) alpha = alpha * q[k];
+      out.mask[t.pix] = 1.0f - alpha;
+      if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
+      if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
       // lean output: only the nearest-face plane, the one slot any caller of the reference
       // reads (loss_utils.py:214, 431); the other K-1 ids stay in registers
-      out.p2f[t.pix] = (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1;
-      return;
+      if (out.kout == 1)
+        out.p2f[t.pix] = (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1;
     }
-    longlong2* o2 = reinterpret_cast<longlong2*>(out.p2f + t.pix * K);  // K even -> 16-B aligned
+    if (out.kout == 1) return;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));  // K even -> 16-byte pieces
+    constexpr int CH = K / 2;                                   // pieces per pixel
+    if constexpr (sizeof(FwdLds) >= (size_t)64 * K * 8) {
+      // The K ids of a pixel are 8K contiguous bytes, so a lane storing its own row hits 64
+      // different cache lines per instruction.  The block's ids are therefore staged in LDS (the
+      // candidate lists are dead by now) in image order -- 8 rows of 64K contiguous bytes -- and
+      // written out with consecutive lanes on consecutive 16-byte pieces.
+      wave_lds_sync();
+      ll2* so = reinterpret_cast<ll2*>(&S);
+      const int slot = (t.yi & 7) * 8 + (t.xi & 7);
 #pragma unroll
-    for (int k2 = 0; k2 < K / 2; ++k2) {
-      longlong2 v;
-      v.x = (key[2 * k2] != KEY_NONE) ? fbase + (long long)(key[2 * k2] & 0xffffffffu) : (long long)-1;
-      v.y = (key[2 * k2 + 1] != KEY_NONE) ? fbase + (long long)(key[2 * k2 + 1] & 0xffffffffu) : (long long)-1;
-      o2[k2] = v;
+      for (int k2 = 0; k2 < CH; ++k2) {
+        ll2 v;
+        v.x = (key[2 * k2] != KEY_NONE) ? fbase + (long long)(key[2 * k2] & 0xffffffffu) : (long long)-1;
+        v.y = (key[2 * k2 + 1] != KEY_NONE) ? fbase + (long long)(key[2 * k2 + 1] & 0xffffffffu) : (long long)-1;
+        so[slot * CH + k2] = v;
+      }
+      wave_lds_sync();
+      const int by = t.yi & ~7, bx = t.xi & ~7;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = i * 64 + t.lane;             // piece index: 8 rows x (8 pixels x CH pieces)
+        const int r = c / (8 * CH), off = c % (8 * CH);
+        if (by + r < H && bx + off / CH < H)
+          reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
+      }
+    } else {
+      if (!t.valid) return;
+      ll2* o2 = reinterpret_cast<ll2*>(out.p2f + t.pix * K);
+#pragma unroll
+      for (int k2 = 0; k2 < CH; ++k2) {
+        ll2 v;
+        v.x = (key[2 * k2] != KEY_NONE) ? fbase + (long long)(key[2 * k2] & 0xffffffffu) : (long long)-1;
+        v.y = (key[2 * k2 + 1] != KEY_NONE) ? fbase + (long long)(key[2 * k2 + 1] & 0xffffffffu) : (long long)-1;
+        o2[k2] = v;
+      }
     }
   }
 }
