@@ -1,0 +1,138 @@
+// Camera hypothesis pipeline of the multiframe trainer in one kernel:
+//   decode     embedding e[7] -> (s = relu(decay*e0 + 1) + 1e-12, t = e1..2, q = normalize(e3..6))
+//              (multiframe/main.py:572-577, == :452-457, predictor.py:248-252)
+//   mirror     blend with the pose of the horizontally flipped image by the frame's mirror flag:
+//              (s, -tx, ty, q_y(pi) * standardize(q)), standardized      (main.py:97-125)
+//   transform  crop/scale augmentation (a, dx, dy, flag) applied to scale and translation
+//              (main.py:128-138)
+// The reference runs this as ~60 elementwise torch kernels on [G*N, 7] tensors per step plus ~100
+// in the backward (the camera embeddings are optimised through it, train_utils.py:186-213); here
+// it is one thread per camera, forward and backward.  Row r of the [G*N, 7] batch belongs to frame
+// r % N (the reference repeats the per-frame flags G times).
+#include "acfm_common.h"
+
+namespace acfm {
+
+struct CamFwd {
+  float s, q[4], b_sign, raw0_sign, nrm;
+  bool relu_on;
+};
+
+__device__ __forceinline__ void cam_forward(const float* __restrict__ e, float decay, float m, const float* __restrict__ tr,
+                                            float* __restrict__ o, CamFwd& c) {
+  const float pre = decay * e[0] + 1.0f;
+  c.relu_on = pre > 0.0f;
+  c.s = fmaxf(pre, 0.0f) + 1e-12f;
+  c.nrm = sqrtf(e[3] * e[3] + e[4] * e[4] + e[5] * e[5] + e[6] * e[6]);
+  const float d = fmaxf(c.nrm, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.q[k] = e[3 + k] / d;
+  // mirrored pose: q_m = standardize(q_y(pi) * standardize(q)), q_y(pi) = (0, 0, 1, 0)
+  c.b_sign = c.q[0] < 0.0f ? -1.0f : 1.0f;
+  const float b0 = c.b_sign * c.q[0], b1 = c.b_sign * c.q[1], b2 = c.b_sign * c.q[2], b3 = c.b_sign * c.q[3];
+  float raw[4] = {-b2, b3, b0, -b1};
+  c.raw0_sign = raw[0] < 0.0f ? -1.0f : 1.0f;
+  const float pose[7] = {c.s, e[1], e[2], c.q[0], c.q[1], c.q[2], c.q[3]};
+  const float mir[7] = {c.s, -e[1], e[2], c.raw0_sign * raw[0], c.raw0_sign * raw[1], c.raw0_sign * raw[2],
+                        c.raw0_sign * raw[3]};
+  float p1[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) p1[k] = (1.0f - m) * pose[k] + mir[k] * m;
+  const float a = tr[0], dx = tr[1], dy = tr[2], f = tr[3];
+  const float nw[7] = {p1[0] * a, p1[1] * a + dx, p1[2] * a + dy, p1[3], p1[4], p1[5], p1[6]};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) o[k] = (1.0f - f) * p1[k] + nw[k] * f;
+}
+
+__global__ void k_camera_fwd(const float* __restrict__ emb, const int64_t* __restrict__ mirror,
+                             const float* __restrict__ transforms, int R, int N, float decay,
+                             float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int n = r % N;
+  float e[7], o[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) e[k] = emb[(size_t)r * 7 + k];
+  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
+  CamFwd c;
+  cam_forward(e, decay, (float)mirror[n], tr, o, c);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) out[(size_t)r * 7 + k] = o[k];
+}
+
+__global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __restrict__ mirror,
+                             const float* __restrict__ transforms, const float* __restrict__ gout, int R,
+                             int N, float decay, float* __restrict__ gemb) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int n = r % N;
+  float e[7], o[7], g[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { e[k] = emb[(size_t)r * 7 + k]; g[k] = gout[(size_t)r * 7 + k]; }
+  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
+  const float m = (float)mirror[n];
+  CamFwd c;
+  cam_forward(e, decay, m, tr, o, c);
+  const float a = tr[0], f = tr[3];
+  // out = (1-f) p1 + f new(p1)
+  float gp1[7];
+  gp1[0] = (1.0f - f) * g[0] + f * g[0] * a;
+  gp1[1] = (1.0f - f) * g[1] + f * g[1] * a;
+  gp1[2] = (1.0f - f) * g[2] + f * g[2] * a;
+#pragma unroll
+  for (int k = 3; k < 7; ++k) gp1[k] = (1.0f - f) * g[k] + f * g[k];
+  // p1 = (1-m) pose + m mir
+  float gpose[7], gmir[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { gpose[k] = (1.0f - m) * gp1[k]; gmir[k] = m * gp1[k]; }
+  float gs = gpose[0] + gmir[0];
+  const float ge1 = gpose[1] - gmir[1], ge2 = gpose[2] + gmir[2];
+  // mir q = raw0_sign * raw, raw = (-b2, b3, b0, -b1), b = b_sign * q
+  const float gr0 = c.raw0_sign * gmir[3], gr1 = c.raw0_sign * gmir[4], gr2 = c.raw0_sign * gmir[5],
+              gr3 = c.raw0_sign * gmir[6];
+  float gq[4] = {gpose[3] + c.b_sign * gr2, gpose[4] - c.b_sign * gr3, gpose[5] - c.b_sign * gr0,
+                 gpose[6] + c.b_sign * gr1};
+  // q = e / max(|e|, eps)
+  float ge[7];
+  if (c.nrm > 1e-12f) {
+    const float dot = c.q[0] * gq[0] + c.q[1] * gq[1] + c.q[2] * gq[2] + c.q[3] * gq[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ge[3 + k] = (gq[k] - c.q[k] * dot) / c.nrm;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ge[3 + k] = gq[k] / 1e-12f;
+  }
+  ge[0] = c.relu_on ? decay * gs : 0.0f;
+  ge[1] = ge1;
+  ge[2] = ge2;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) gemb[(size_t)r * 7 + k] = ge[k];
+}
+
+}  // namespace acfm
+
+using namespace acfm;
+
+extern "C" {
+
+int acfm_camera_pipeline(const float* emb, const int64_t* mirror_flag, const float* transforms, int R, int N,
+                         float scale_lr_decay, float* cams, void* stream) {
+  if (!emb || !mirror_flag || !transforms || !cams || R <= 0 || N <= 0 || R % N != 0) return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_camera_fwd, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, emb, mirror_flag,
+                     transforms, R, N, scale_lr_decay, cams);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, const float* transforms,
+                                  const float* grad_cams, int R, int N, float scale_lr_decay, float* grad_emb,
+                                  void* stream) {
+  if (!emb || !mirror_flag || !transforms || !grad_cams || !grad_emb || R <= 0 || N <= 0 || R % N != 0)
+    return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_camera_bwd, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, emb, mirror_flag,
+                     transforms, grad_cams, R, N, scale_lr_decay, grad_emb);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+}  // extern "C"

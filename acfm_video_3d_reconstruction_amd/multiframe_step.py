@@ -71,9 +71,13 @@ class MultiframeStep(nn.Module):
     def hypothesis_cameras(self, frames_idx, mirror_flag, transforms, detach=False):
         G = self.opts.num_guesses
         cams = torch.stack([emb(frames_idx) for emb in self.cameras]).reshape(G, -1, 7)
-        cam_pred = harness.decode_cameras(cams, self.opts.scale_lr_decay).reshape(-1, 7)
-        cam_pred = harness.mirror_cameras(cam_pred, None, mirror_flag.repeat(G)[:, None])
-        cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
+        if cams.is_cuda:       # decode + mirror + transform fused (csrc/acfm_camera.hip)
+            from . import ops
+            cam_pred = ops.camera_pipeline(cams, mirror_flag, transforms, self.opts.scale_lr_decay)
+        else:
+            cam_pred = harness.decode_cameras(cams, self.opts.scale_lr_decay).reshape(-1, 7)
+            cam_pred = harness.mirror_cameras(cam_pred, None, mirror_flag.repeat(G)[:, None])
+            cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
         return cam_pred.detach() if detach else cam_pred
 
     def _silhouette_terms(self, pred_v, faces, cam, batch, G):

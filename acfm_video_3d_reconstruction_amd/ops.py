@@ -192,6 +192,47 @@ def deform_solve(L, lbs_logits, check=False):
     return _DeformSolve.apply(L, lbs_logits, bool(check))
 
 
+# ------------------------------------------------------------------------------ cameras
+class _CameraPipeline(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, mirror_flag, transforms, decay):
+        _lib.require_gpu(emb, mirror_flag, transforms)
+        e = _f32c(emb)
+        R = e.numel() // 7
+        mf = mirror_flag.detach().reshape(-1).to(torch.int64).contiguous()
+        tr = _f32c(transforms).reshape(-1, 4)
+        N = mf.numel()
+        if tr.shape[0] != N or R % N != 0:
+            raise ValueError("camera rows %d must be a multiple of the %d frames (transforms %s)"
+                             % (R, N, tuple(tr.shape)))
+        out = torch.empty((R, 7), dtype=torch.float32, device=e.device)
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.lib().acfm_camera_pipeline(_lib.ptr(e), _lib.ptr(mf), _lib.ptr(tr), R, N, float(decay),
+                                                       _lib.ptr(out), _lib.cur_stream(e.device)),
+                       "acfm_camera_pipeline")
+        ctx.save_for_backward(e, mf, tr)
+        ctx.decay = float(decay)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        e, mf, tr = ctx.saved_tensors
+        R, N = e.numel() // 7, mf.numel()
+        g = _f32c(g)
+        ge = torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.lib().acfm_camera_pipeline_backward(
+                _lib.ptr(e), _lib.ptr(mf), _lib.ptr(tr), _lib.ptr(g), R, N, ctx.decay, _lib.ptr(ge),
+                _lib.cur_stream(e.device)), "acfm_camera_pipeline_backward")
+        return ge, None, None, None
+
+
+def camera_pipeline(cam_emb, mirror_flag, transforms, scale_lr_decay=1.0):
+    """Camera embeddings [G,N,7] (or [R,7], row r of frame r % N) -> cameras [R,7]: decode, mirror by
+    the per-frame flag [N], crop/scale transform [N,4] (multiframe/main.py:551-584) in one kernel."""
+    return _CameraPipeline.apply(cam_emb, mirror_flag, transforms, scale_lr_decay)
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod

@@ -98,6 +98,20 @@ int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, i
 int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
                                int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
 
+/* ---- camera hypothesis pipeline --------------------------------------------------------
+ * replaces the camera decode + mirror_cameras + transform_cameras chain of ShapeTrainer.forward /
+ * warmup (multiframe/main.py:551-584, 452-466; the functions at :97-138): per camera row
+ *   (s, t, q) = (relu(decay*e0 + 1) + 1e-12, e1..2, normalize(e3..6));
+ *   blended by the frame's mirror flag with (s, -tx, ty, standardize(q_y(pi) * standardize(q)));
+ *   then (s*a, tx*a + dx, ty*a + dy, q) blended by the frame's transform flag.
+ *   emb [R,7] f32 (R = G*N rows, row r belongs to frame r % N), mirror_flag [N] i64,
+ *   transforms [N,4] f32 (a, dx, dy, flag) -> cams [R,7];  backward: grad_cams -> grad_emb. */
+int acfm_camera_pipeline(const float* emb, const int64_t* mirror_flag, const float* transforms, int R, int N,
+                         float scale_lr_decay, float* cams, void* stream);
+int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, const float* transforms,
+                                  const float* grad_cams, int R, int N, float scale_lr_decay, float* grad_emb,
+                                  void* stream);
+
 /* ---- template deformation solve ------------------------------------------------------
  * replaces the per-frame torch.cholesky / torch.cholesky_solve of multiframe/main.py:586-609
  * (also optimization/main.py:474-496, nnutils/predictor.py:260-276): with A = softmax(lbs, dim 0)^T

@@ -395,3 +395,35 @@ def test_multiframe_step_hipgraph_matches_eager(meshes):
         moved += int(np.abs(de).max() > 0)
         np.testing.assert_allclose(dg, de, rtol=0, atol=2e-2 * float(np.abs(de).max()) + 1e-10, err_msg=name)
     assert moved >= 5
+
+
+def test_camera_pipeline_fused_vs_harness():
+    """a17: decode + mirror_cameras + transform_cameras in one kernel (csrc/acfm_camera.hip) against
+    the torch composition of harness.py (itself checked against the reference's golden vectors in
+    test_shim_and_harness.py), values and gradients, all flag combinations."""
+    from acfm_video_3d_reconstruction_amd import harness, ops
+    d = _d()
+    torch.manual_seed(3)
+    G, N = 5, 12
+    for decay in (1.0, 0.05):
+        emb = torch.randn(G, N, 7, device=d)
+        emb[0, 0, 0] = -30.0                      # relu off
+        emb[1, 1, 3:] = 0.0                       # zero quaternion: the eps branch of normalize
+        mirror = torch.tensor([0, 1] * (N // 2), device=d)
+        tr = torch.rand(N, 4, device=d)
+        tr[:, 3] = torch.tensor([0, 0, 1, 1] * (N // 4), device=d).float()
+        w = torch.randn(G * N, 7, device=d)
+        a = emb.clone().requires_grad_(True)
+        out = ops.camera_pipeline(a, mirror, tr, decay)
+        (out * w).sum().backward()
+        b = emb.clone().requires_grad_(True)
+        ref = harness.decode_cameras(b, decay).reshape(-1, 7)
+        ref = harness.mirror_cameras(ref, None, mirror.repeat(G)[:, None])
+        ref = harness.transform_cameras(ref, None, tr.repeat(G, 1))
+        (ref * w).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+        ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+        keep = np.ones((G, N), bool)
+        keep[1, 1] = False                        # d normalize at 0: 1/eps-scaled, compared separately below
+        np.testing.assert_allclose(ga[keep], gb[keep], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ga[1, 1, :3], gb[1, 1, :3], rtol=1e-4, atol=1e-5)
