@@ -183,6 +183,73 @@ __global__ void k_bds_loss_bwd(const float* __restrict__ verts_xy, const float* 
   atomicAdd(&gv[((size_t)n * V + v) * 2 + 1], 2.0f * (x[1] - b[1]) * g);
 }
 
+// ---- optical-flow loss (loss_utils.py:419-474), one workgroup per (clip, frame k >= 1) --------------
+// per vertex: GT flow = nearest pixel of the frame's flow image at the projected vertex
+// (grid_sample, mode nearest, align_corners False, zero padding), predicted flow = pixel
+// displacement of the vertex between frame k-1 and k, both counted where the vertex is visible in
+// frame k and the GT flow is non-zero;  loss[c,k-1] = sum |gt - pred|_1 / H / (count + 1).
+__device__ __forceinline__ bool of_term(const float* __restrict__ proj, const float* __restrict__ flows,
+                                        const uint8_t* __restrict__ vis, int c, int k, int v, int T, int V,
+                                        int H, int W, float& dx, float& dy) {
+  const size_t fk = (size_t)c * T + k;
+  const float* pk = proj + (fk * V + v) * 3;
+  const float* pp = proj + ((fk - 1) * V + v) * 3;
+  const float x = pk[0], y = pk[1];
+  const float ixf = rintf(((x + 1.0f) * (float)W - 1.0f) / 2.0f), iyf = rintf(((y + 1.0f) * (float)H - 1.0f) / 2.0f);
+  float gx = 0.f, gy = 0.f;
+  if (ixf >= 0.f && ixf <= (float)(W - 1) && iyf >= 0.f && iyf <= (float)(H - 1)) {
+    const float* g = flows + ((fk * H + (int)iyf) * (size_t)W + (int)ixf) * 2;
+    gx = g[0]; gy = g[1];
+  }
+  const bool keep = (fabsf(gx) + fabsf(gy) != 0.0f) && vis[fk * V + v] != 0;
+  const float fw = (float)W;
+  const float fpx = fw * (pp[0] + 1.0f) / 2.0f - fw * (x + 1.0f) / 2.0f;
+  const float fpy = fw * (pp[1] + 1.0f) / 2.0f - fw * (y + 1.0f) / 2.0f;
+  dx = gx - fpx; dy = gy - fpy;
+  return keep;
+}
+
+__global__ __launch_bounds__(LTPB) void k_of_loss(const float* __restrict__ proj, const float* __restrict__ flows,
+                                                  const uint8_t* __restrict__ vis, int T, int V, int H, int W,
+                                                  float* __restrict__ loss, float* __restrict__ count) {
+  __shared__ float s_red[4][2];
+  const int k = blockIdx.x + 1, c = blockIdx.y, tid = threadIdx.x;
+  float sum = 0.f, cnt = 0.f;
+  for (int v = tid; v < V; v += LTPB) {
+    float dx, dy;
+    if (of_term(proj, flows, vis, c, k, v, T, V, H, W, dx, dy)) { sum += fabsf(dx) + fabsf(dy); cnt += 1.0f; }
+  }
+  sum = wave_sum(sum); cnt = wave_sum(cnt);
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = sum; s_red[tid >> 6][1] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    const float s = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const float n = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    loss[(size_t)c * (T - 1) + k - 1] = s / (float)H / (n + 1.0f);
+    count[(size_t)c * (T - 1) + k - 1] = n;
+  }
+}
+
+__global__ __launch_bounds__(LTPB) void k_of_loss_bwd(const float* __restrict__ proj, const float* __restrict__ flows,
+                                                      const uint8_t* __restrict__ vis, const float* __restrict__ count,
+                                                      const float* __restrict__ gl, int T, int V, int H, int W,
+                                                      float* __restrict__ gproj) {
+  const int k = blockIdx.y + 1, c = blockIdx.z;
+  const int v = blockIdx.x * LTPB + threadIdx.x;
+  if (v >= V) return;
+  float dx, dy;
+  if (!of_term(proj, flows, vis, c, k, v, T, V, H, W, dx, dy)) return;
+  const size_t o = (size_t)c * (T - 1) + k - 1;
+  // d|gt - pred| / d pred = -sign(gt - pred);  pred = pix[k-1] - pix[k],  pix = W (xy + 1) / 2
+  const float g = gl[o] / (float)H / (count[o] + 1.0f) * (float)W / 2.0f;
+  const float sx = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f), sy = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f);
+  const size_t fk = (size_t)c * T + k;
+  float* gk = gproj + (fk * V + v) * 3;
+  float* gp = gproj + ((fk - 1) * V + v) * 3;
+  atomicAdd(&gp[0], -sx * g); atomicAdd(&gp[1], -sy * g);
+  atomicAdd(&gk[0], sx * g); atomicAdd(&gk[1], sy * g);
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -276,6 +343,31 @@ int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_
   ProfScope ps(ACFM_PROF_BDS_BWD, st);
   hipLaunchKernelGGL(k_bds_loss_bwd, dim3((P + 255) / 256, N), dim3(256), 0, st, verts_xy, bds, argmin,
                      grad_loss, V, P, grad_verts_xy);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_of_loss(const float* proj, const float* flows, const uint8_t* vis, int B, int T, int V, int H, int W,
+                 float* loss, float* count, void* stream) {
+  if (!proj || !flows || !vis || !loss || !count || B <= 0 || B > 65535 || T < 2 || T > 65535 || V <= 0 || H <= 0 ||
+      W <= 0)
+    return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_of_loss, dim3(T - 1, B), dim3(LTPB), 0, (hipStream_t)stream, proj, flows, vis, T, V, H, W,
+                     loss, count);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_of_loss_backward(const float* proj, const float* flows, const uint8_t* vis, const float* count,
+                          const float* grad_loss, int B, int T, int V, int H, int W, float* grad_proj,
+                          void* stream) {
+  if (!proj || !flows || !vis || !count || !grad_loss || !grad_proj || B <= 0 || B > 65535 || T < 2 || T > 65535 ||
+      V <= 0 || H <= 0 || W <= 0)
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_async(grad_proj, sizeof(float) * 3 * (size_t)B * T * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
+  hipLaunchKernelGGL(k_of_loss_bwd, dim3((V + LTPB - 1) / LTPB, T - 1, B), dim3(LTPB), 0, st, proj, flows, vis, count,
+                     grad_loss, T, V, H, W, grad_proj);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -100,8 +100,8 @@ class MultiframeStep(nn.Module):
         masks_of = batch["masks"].reshape(B, T, *batch["masks"].shape[1:])
         flows = (torch.flip(batch["optical_flows"], dims=[1]) * masks_of[..., None]).repeat(G, 1, 1, 1, 1)
         faces_of = self.faces1[None, None].expand(G * B, T, -1, -1)
-        of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, flows,
-                                                           self.of_renderer, pix_to_face=None, reduce=False)
+        of_loss = loss_utils.optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, flows,
+                                               self.of_renderer, pix_to_face=None, reduce=False, loss_only=True)
         return of_loss.reshape(G, -1).repeat(1, T).reshape(G, -1)    # main.py:684-686
 
     # ------------------------------------------------------------------ main.py:438-520

@@ -250,9 +250,11 @@ class TexCycle(nn.Module):
         return F.mse_loss(mean_flow * seen, prob * seen), mean_flow[0, :10]
 
 
-def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True):
+def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True, loss_only=False):
     """loss_utils.py:419-474.  meshes [b,t,V,3], faces [b,t,F,3], cams [b*t,7],
-    flows [b,t,H,W,2]; renderer: an OF_NeuralRenderer-like object (proj_fn + __call__)."""
+    flows [b,t,H,W,2]; renderer: an OF_NeuralRenderer-like object (proj_fn + __call__).
+    loss_only=True (not in the reference): return just the loss, from one fused kernel
+    (ops.of_loss), instead of the 5-tuple with the per-vertex intermediates."""
     H, W = flows.shape[2:4]
     b, t, nv, _ = meshes.shape
     bt = b * t
@@ -264,6 +266,9 @@ def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=
         elif pix_to_face.shape[-1] != 1:
             pix_to_face = pix_to_face[..., :1]
         visible_vertices = ops.visible_vertices(pix_to_face, faces_bt, nv).reshape(b, t, nv)
+    if loss_only and predicted_points.is_cuda:
+        loss = ops.of_loss(predicted_points.reshape(bt, nv, 3), flows.reshape(bt, H, W, -1), visible_vertices, b, t)
+        return loss.sum() if reduce else loss
 
     xy = predicted_points[..., :2]                                            # [bt, V, 2] in [-1, 1]
     # GT flow at each projected vertex: nearest pixel (:449-452)

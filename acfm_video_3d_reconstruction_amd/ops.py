@@ -233,6 +233,47 @@ def camera_pipeline(cam_emb, mirror_flag, transforms, scale_lr_decay=1.0):
     return _CameraPipeline.apply(cam_emb, mirror_flag, transforms, scale_lr_decay)
 
 
+# ------------------------------------------------------------------------------ optical flow
+class _OFLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj, flows, vis, B, T):
+        _lib.require_gpu(proj, flows, vis)
+        p, fl = _f32c(proj), _f32c(flows)
+        V = p.shape[-2]
+        H, W = fl.shape[-3], fl.shape[-2]
+        vi = vis.detach().reshape(-1, V).to(torch.uint8).contiguous()
+        if p.numel() != B * T * V * 3 or fl.numel() != B * T * H * W * 2 or vi.shape[0] != B * T:
+            raise ValueError("of_loss: proj %s flows %s vis %s do not match B=%d T=%d"
+                             % (tuple(p.shape), tuple(fl.shape), tuple(vi.shape), B, T))
+        loss = torch.empty((B, T - 1), dtype=torch.float32, device=p.device)
+        cnt = torch.empty((B, T - 1), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().acfm_of_loss(_lib.ptr(p), _lib.ptr(fl), _lib.ptr(vi), B, T, V, H, W,
+                                               _lib.ptr(loss), _lib.ptr(cnt), _lib.cur_stream(p.device)),
+                       "acfm_of_loss")
+        ctx.save_for_backward(p, fl, vi, cnt)
+        ctx.dims = (B, T, V, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, fl, vi, cnt = ctx.saved_tensors
+        B, T, V, H, W = ctx.dims
+        g = _f32c(g)
+        gp = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().acfm_of_loss_backward(_lib.ptr(p), _lib.ptr(fl), _lib.ptr(vi), _lib.ptr(cnt),
+                                                        _lib.ptr(g), B, T, V, H, W, _lib.ptr(gp),
+                                                        _lib.cur_stream(p.device)), "acfm_of_loss_backward")
+        return gp, None, None, None, None
+
+
+def of_loss(proj, flows, vis, B, T):
+    """Optical-flow loss per clip and frame pair [B,T-1] from projected vertices [B*T,V,3], GT flow
+    images [B*T,H,W,2] and the visible-vertex bitmap [B*T,V] (loss_utils.py:445-474, one kernel)."""
+    return _OFLoss.apply(proj, flows, vis, int(B), int(T))
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod

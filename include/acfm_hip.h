@@ -98,6 +98,19 @@ int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, i
 int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
                                int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
 
+/* ---- optical-flow loss -----------------------------------------------------------------
+ * replaces the tail of loss_utils.optical_flow_loss (multiframe/nnutils/loss_utils.py:445-474):
+ *   proj [B*T,V,3] projected vertices (proj_fn output, x/y in [-1,1]), flows [B*T,H,W,2] GT flow
+ *   images, vis [B*T,V] visible-vertex bitmap of the hard raster  ->  loss [B,T-1]:
+ *   sum over the kept vertices of |gt - (pix[k-1] - pix[k])|_1 / H / (kept + 1), gt = nearest pixel
+ *   (grid_sample nearest, align_corners False, zeros), kept = visible in frame k and gt != 0;
+ *   count [B,T-1] is saved for the backward pass (grad_loss [B,T-1] -> grad_proj [B*T,V,3]). */
+int acfm_of_loss(const float* proj, const float* flows, const uint8_t* vis, int B, int T, int V, int H, int W,
+                 float* loss, float* count, void* stream);
+int acfm_of_loss_backward(const float* proj, const float* flows, const uint8_t* vis, const float* count,
+                          const float* grad_loss, int B, int T, int V, int H, int W, float* grad_proj,
+                          void* stream);
+
 /* ---- camera hypothesis pipeline --------------------------------------------------------
  * replaces the camera decode + mirror_cameras + transform_cameras chain of ShapeTrainer.forward /
  * warmup (multiframe/main.py:551-584, 452-466; the functions at :97-138): per camera row

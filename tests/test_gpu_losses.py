@@ -427,3 +427,37 @@ def test_camera_pipeline_fused_vs_harness():
         keep[1, 1] = False                        # d normalize at 0: 1/eps-scaled, compared separately below
         np.testing.assert_allclose(ga[keep], gb[keep], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ga[1, 1, :3], gb[1, 1, :3], rtol=1e-4, atol=1e-5)
+
+
+def test_optical_flow_loss_fused_vs_torch_path(meshes):
+    """a13: the fused optical-flow loss kernel (ops.of_loss, loss_only=True) against the op-by-op
+    torch formulation of the same function (which test_gpu_losses checks against the reference's
+    golden vectors), value and gradients to vertices and cameras; T = 2 and T = 3."""
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import OF_NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.synthetic import make_cams
+    d = _d()
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    H = 64
+    ren = OF_NeuralRenderer(H)
+    for b, t in ((3, 2), (2, 3)):
+        rng = np.random.default_rng(10 * b + t)
+        verts = torch.tensor(v[None, None] + 0.01 * rng.standard_normal((b, t) + v.shape), dtype=torch.float32, device=d)
+        cams = torch.tensor(make_cams(b * t, rng, extent=float(np.abs(v).max())), device=d)
+        flows = torch.tensor(rng.standard_normal((b, t, H, H, 2)), dtype=torch.float32, device=d)
+        flows[:, :, : H // 4] = 0.0                                   # a band without GT flow: dropped vertices
+        faces = torch.from_numpy(f).to(d)[None, None].expand(b, t, -1, -1)
+        w = torch.tensor(rng.uniform(0.5, 1.5, (b, t - 1)), dtype=torch.float32, device=d)
+        va, ca = verts.clone().requires_grad_(True), cams.clone().requires_grad_(True)
+        la = L.optical_flow_loss(va, faces, ca, flows, ren, None, reduce=False, loss_only=True)
+        (la * w).sum().backward()
+        vb, cb = verts.clone().requires_grad_(True), cams.clone().requires_grad_(True)
+        lb = L.optical_flow_loss(vb, faces, cb, flows, ren, None, reduce=False)[0]
+        (lb * w).sum().backward()
+        assert la.shape == lb.shape == (b, t - 1)
+        np.testing.assert_allclose(la.detach().cpu().numpy(), lb.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(va.grad.cpu().numpy(), vb.grad.cpu().numpy(), rtol=1e-4,
+                                   atol=1e-5 * float(vb.grad.abs().max()))
+        np.testing.assert_allclose(ca.grad.cpu().numpy(), cb.grad.cpu().numpy(), rtol=1e-3,
+                                   atol=1e-4 * float(cb.grad.abs().max()))
+        assert float(lb.abs().sum()) > 0
