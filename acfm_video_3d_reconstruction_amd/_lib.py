@@ -39,10 +39,10 @@ SIGNATURES = {
                                _sz, _i, _vp]),
     "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "acfm_tex_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
-                              _vp, _sz, _i, _f, _vp]),
+                              _vp, _sz, _i, _f, _i, _vp]),
     "acfm_vertex_color_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
                                        _i, _f, _vp]),
-    "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -651,6 +651,7 @@ struct FwdOut {
   int R;
   float gamma;
   float box_shrink;          // > 0: the workspace was set up with a larger blur margin; boxes are tightened by this much
+  int atlas_n;               // number of distinct atlases: mesh n samples atlas n % atlas_n
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
         const bool below = ((bestb0 + bestb1) * (float)R - ((float)ix + (float)iy)) <= 1.0f;
         if (!below) { ix = R - 1 - ix; iy = R - 1 - iy; }
         ix = min(max(ix, 0), R - 1); iy = min(max(iy, 0), R - 1);
-        const size_t ti = (((size_t)(fbase + f) * R + iy) * R + ix);
+        const size_t ti = ((((size_t)(n % out.atlas_n) * F + f) * R + iy) * R + ix);
         const float eps = 1e-10f, znear = 1.0f, zfar = 100.0f;
         const float prob = sigmoid_neg(bestsd, sigma);
         const float z_inv = (zfar - zb) / (zfar - znear);
@@ -1315,11 +1316,12 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
                      const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
                      float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
-                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, void* stream) {
+                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch, void* stream) {
   if (!verts_world || !faces || !cams || !atlas || !imgs || !sil || !pix_to_face || !texel_idx || !wsp)
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
-  if ((size_t)N * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;  // texel_idx is int32
+  if (atlas_batch <= 0 || N % atlas_batch != 0) return ACFM_E_BADARG;
+  if ((size_t)atlas_batch * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;  // texel_idx is int32
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -1332,6 +1334,7 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
+  out.atlas_n = atlas_batch;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
   hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
@@ -1357,7 +1360,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
   FwdOut out = {};
   out.dbg = g_dbg;
   out.p2f = pix_to_face;
-  out.vrgb = verts_rgb; out.V = V;
+  out.vrgb = verts_rgb; out.V = V; out.atlas_n = N;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
   out.atlas = verts_rgb;  // never dereferenced when vrgb is set
@@ -1369,11 +1372,13 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
 }
 
 int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R,
-                      float* grad_atlas, void* stream) {
-  if (!grad_imgs || !texel_idx || !grad_atlas || N <= 0 || F <= 0 || H <= 0 || R <= 0) return ACFM_E_BADARG;
+                      int atlas_batch, float* grad_atlas, void* stream) {
+  if (!grad_imgs || !texel_idx || !grad_atlas || N <= 0 || F <= 0 || H <= 0 || R <= 0 || atlas_batch <= 0 ||
+      N % atlas_batch != 0)
+    return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * H * H;
-  if (zero_async(grad_atlas, sizeof(float) * 3 * (size_t)N * F * R * R, st) != ACFM_OK)
+  if (zero_async(grad_atlas, sizeof(float) * 3 * (size_t)atlas_batch * F * R * R, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_TEX_BWD, st);
   hipLaunchKernelGGL(k_tex_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grad_imgs,

@@ -164,7 +164,7 @@ class MultiframeStep(nn.Module):
         if textures is not None and imgs is not None:
             # texture branch on detached geometry, original + mirrored camera (main.py:627-636, 655-662;
             # the LPIPS part of the reference's texture loss is out of scope)
-            tex = textures.repeat(G, 1, 1, 1, 1)
+            tex = textures    # [N,...] shared by the G hypotheses of a frame: the op indexes n % N (= repeat(G))
             tex_pred, _, _ = self.tex_renderer(pred_v.detach(), faces, cam, textures=tex)
             imgs_f, cam_f, _, masks_f = harness.mirror_sample(imgs, cam, mask_pred, batch["masks"])
             tex_pred_f, _, _ = self.tex_renderer(pred_v.detach(), faces, cam_f, textures=tex)

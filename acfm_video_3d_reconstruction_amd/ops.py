@@ -362,8 +362,10 @@ class _TexRender(torch.autograd.Function):
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
-        if a.dim() != 5 or a.shape[0] != N or a.shape[1] != F or a.shape[2] != a.shape[3] or a.shape[4] != 3:
-            raise ValueError("atlas must be [N,F,R,R,3], got %s" % (tuple(a.shape),))
+        NA = a.shape[0] if a.dim() == 5 else 0
+        if a.dim() != 5 or NA == 0 or N % NA != 0 or a.shape[1] != F or a.shape[2] != a.shape[3] or a.shape[4] != 3:
+            raise ValueError("atlas must be [N,F,R,R,3] (or [N/G,F,R,R,3], shared by G hypotheses), got %s for "
+                             "N=%d F=%d" % (tuple(a.shape), N, F))
         R = a.shape[2]
         imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
         sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
@@ -375,10 +377,10 @@ class _TexRender(torch.autograd.Function):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
                 float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
-                _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur),
+                _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
                 _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
-        ctx.cfg = (N, F, H, R)
+        ctx.cfg = (N, F, H, R, NA)
         ctx.mark_non_differentiable(sil, p2f)
         ctx.set_materialize_grads(False)
         return imgs, sil, p2f
@@ -386,13 +388,13 @@ class _TexRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gimgs, _gs, _gp):
         (tidx,) = ctx.saved_tensors
-        N, F, H, R = ctx.cfg
+        N, F, H, R, NA = ctx.cfg
         ga = None
         if ctx.needs_input_grad[3] and gimgs is not None:
             g = _f32c(gimgs)
-            ga = torch.empty((N, F, R, R, 3), dtype=torch.float32, device=g.device)
+            ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=g.device)
             with torch.cuda.device(g.device):
-                _lib.check(_lib.lib().acfm_tex_backward(_lib.ptr(g), _lib.ptr(tidx), N, F, H, R,
+                _lib.check(_lib.lib().acfm_tex_backward(_lib.ptr(g), _lib.ptr(tidx), N, F, H, R, NA,
                                                         _lib.ptr(ga), _lib.cur_stream(g.device)),
                            "acfm_tex_backward")
         # geometry / camera: integer texel lookup and K=1 blending send (numerically) no
@@ -401,7 +403,10 @@ class _TexRender(torch.autograd.Function):
 
 
 def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
-    """Atlas-textured hard render: -> (imgs [N,3,H,H], sil [N,H,H], pix_to_face [N,H,H,1])."""
+    """Atlas-textured hard render: -> (imgs [N,3,H,H], sil [N,H,H], pix_to_face [N,H,H,1]).
+    atlas [N,F,R,R,3], or [N/G,F,R,R,3] when G hypotheses of every frame share the frame's
+    texture (mesh n samples atlas n % (N/G); equivalent to atlas.repeat(G,1,1,1,1) without the
+    copies, gradients of the G renders summed)."""
     return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z)
 
 

@@ -196,12 +196,16 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
  * ws_ready != 0: `ws` already holds the face setup of THE SAME verts / faces / cams / H /
  * offset_z, left there by acfm_sil_forward with blur_radius = ws_blur (the reference renders the
  * silhouette and the texture of one prediction back to back, main.py:616-636): projection and
- * face setup are skipped and the blur-expanded boxes tightened by sqrt(ws_blur). */
+ * face setup are skipped and the blur-expanded boxes tightened by sqrt(ws_blur).
+ * atlas_batch: number of distinct atlases, atlas [atlas_batch,F,R,R,3]; mesh n samples atlas
+ * n % atlas_batch (the trainer renders G camera hypotheses of every frame with the frame's one
+ * texture, textures.repeat(G, ...) at main.py:627-636: atlas_batch = N / G spares the copies, and
+ * the backward accumulates the G renders straight into the one gradient). */
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
                      const float* atlas, int N, int V, int F, int H, int R, float sigma,
                      float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
                      int32_t* texel_idx, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
-                     void* stream);
+                     int atlas_batch, void* stream);
 /* NeuralRenderer.forward with atlas=False (multiframe/nnutils/nmr.py:177-179, used by
  * utils/bird_vis.py for visualisation): Textures(verts_rgb) = barycentric interpolation of
  * per-vertex colours verts_rgb [N,V,3]; forward only.  Workspace: raster workspace + 4*N*H*H. */
@@ -211,7 +215,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
                               int64_t* pix_to_face, void* ws, size_t ws_bytes, int ws_ready, float ws_blur, void* stream);
 /* grad_imgs [N,3,H,H] -> grad_atlas [N,F,R,R,3] (zeroed here, then scatter-added).
  * Integer texel indexing sends no gradient to geometry. */
-int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R,
+int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R, int atlas_batch,
                       float* grad_atlas, void* stream);
 
 /* ---- fused silhouette losses ---------------------------------------------------------

@@ -200,6 +200,31 @@ def test_texture_render_takes_over_the_silhouette_setup(meshes):
         np.testing.assert_array_equal(moved[2].cpu().numpy(), ref2[2])
 
 
+def test_texture_atlas_shared_by_hypotheses(meshes):
+    """atlas [N/G,...] for G*N/G meshes == atlas.repeat(G,...): same images, gradient = sum over the
+    G copies (acfm_tex_forward / _backward, atlas_batch)."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    G, n0, H, R = 3, 2, 64, 4
+    verts, f, cams = _setup(meshes, "bird", G * n0, 47)
+    rng = np.random.default_rng(48)
+    atlas = torch.tensor(rng.uniform(0, 1, (n0, f.shape[0], R, R, 3)).astype(np.float32), device=d)
+    tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+    faces = torch.from_numpy(f)[None].to(d).expand(G * n0, -1, -1)
+    w = torch.tensor(rng.standard_normal((G * n0, 3, H, H)).astype(np.float32), device=d)
+    a1 = atlas.clone().requires_grad_(True)
+    out1 = ops.tex_render(tv, faces, tc, a1, H)
+    (out1[0] * w).sum().backward()
+    a2 = atlas.clone().requires_grad_(True)
+    out2 = ops.tex_render(tv, faces, tc, a2.repeat(G, 1, 1, 1, 1), H)
+    (out2[0] * w).sum().backward()
+    for x, y in zip(out1, out2):
+        assert torch.equal(x, y)
+    np.testing.assert_allclose(a1.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.tex_render(tv, faces, tc, atlas[:1].repeat(4, 1, 1, 1, 1), H)      # 6 meshes, 4 atlases
+
+
 def test_silhouette_nearest_plane_only(meshes):
     """pix_to_face_slots=1: same mask, same nearest face, same gradients, 1/20 of the id traffic."""
     from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
