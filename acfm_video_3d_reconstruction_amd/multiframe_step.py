@@ -27,7 +27,7 @@ from .pytorch3d_shim.structures import Meshes
 DEFAULTS = dict(num_frames=2, num_guesses=8, num_lbs=15, kp_loss_wt=0., of_loss_wt=1., mask_loss_wt=1.,
                 rigid_wt=0.5, deform_reg_wt=1., handle_deform_reg_wt=0., boundaries_reg_wt=1., edt_reg_wt=0.1,
                 bdt_reg_wt=2., triangle_reg_wt=0.1, tex_loss_wt=.5, scale_lr_decay=0.05, optimize_deform=False,
-                optimize_deform_lr=100., drop_hypothesis=False, texture=False)
+                optimize_deform_lr=100., drop_hypothesis=False, texture=False, cam_loss_wt=2., deform_loss_wt=2.)
 
 
 def _y_rotation_quats(num_guesses):
@@ -43,6 +43,7 @@ class MultiframeStep(nn.Module):
         o.update(opts)
         self.opts = SimpleNamespace(**o)
         G = self.opts.num_guesses
+        self.num_cameras = G          # embeddings; opts.num_guesses may later drop below it (train_utils.py:236-241)
         q0 = _y_rotation_quats(G)
         self.cameras = nn.ModuleList()
         for g in range(G):                                       # mesh_net.py:436-444
@@ -67,10 +68,26 @@ class MultiframeStep(nn.Module):
         self.tex_renderer = NeuralRenderer(img_size)
         self.of_renderer = OF_NeuralRenderer(img_size)
 
+    def set_num_guesses(self, k):
+        """train_utils.py:236-241: after the first epochs only the k most probable hypotheses of
+        every frame are rendered (opts.drop_hypothesis)."""
+        self.opts.num_guesses = max(1, min(int(k), self.num_cameras))
+
+    def selected_hypotheses(self, frames_idx):
+        """main.py:541-548: indices [k,B,T] of the k most probable camera embeddings of each frame,
+        or None when all of them are active."""
+        if not self.opts.drop_hypothesis or self.opts.num_guesses >= self.num_cameras:
+            return None
+        w = self.prob_embeddings.weight.data[frames_idx]                       # [B,T,G_all]
+        return w.topk(self.opts.num_guesses, largest=True, dim=-1, sorted=True)[1].permute(2, 0, 1)
+
     # ------------------------------------------------------------------ cameras (main.py:551-584)
-    def hypothesis_cameras(self, frames_idx, mirror_flag, transforms, detach=False):
+    def hypothesis_cameras(self, frames_idx, mirror_flag, transforms, detach=False, selected=None):
         G = self.opts.num_guesses
-        cams = torch.stack([emb(frames_idx) for emb in self.cameras]).reshape(G, -1, 7)
+        cams = torch.stack([emb(frames_idx) for emb in self.cameras])          # [G_all,B,T,7]
+        if selected is not None:                                               # main.py:568-570
+            cams = torch.gather(cams, 0, selected[..., None].expand(-1, -1, -1, 7))
+        cams = cams.reshape(G, -1, 7)
         if cams.is_cuda:       # decode + mirror + transform fused (csrc/acfm_camera.hip)
             from . import ops
             cam_pred = ops.camera_pipeline(cams, mirror_flag, transforms, self.opts.scale_lr_decay)
@@ -129,22 +146,29 @@ class MultiframeStep(nn.Module):
         return total.mean(), probs
 
     # ------------------------------------------------------------------ main.py:523-765
-    def forward(self, batch, delta_v_res, textures=None, imgs=None, detach_camera=False, drop_deform=False):
-        """delta_v_res [N,K_h,3]: handle offsets predicted by the (out-of-scope) encoder head.
-        Returns (total_loss, dict of the reference's named terms)."""
+    def forward(self, batch, delta_v_res, textures=None, imgs=None, detach_camera=False, drop_deform=False,
+                predicted_camera=None):
+        """delta_v_res [N,K_h,3]: handle offsets predicted by the (out-of-scope) encoder head;
+        predicted_camera [N,7] (optional): output of its camera head, pulled towards the most
+        probable hypothesis (main.py:753-762).  Returns (total_loss, dict of the reference's named terms)."""
         o = self.opts
         G, T = o.num_guesses, o.num_frames
         N = delta_v_res.shape[0]
+        selected = self.selected_hypotheses(batch["frames_idx"])
         cam = self.hypothesis_cameras(batch["frames_idx"], batch["mirror_flag"], batch["transforms"],
-                                      detach=detach_camera)
-        # deformation (main.py:586-609): delta = 0 when drop_deform, embeddings when optimize_deform
-        if drop_deform:
-            delta = torch.zeros_like(delta_v_res)
-        elif o.optimize_deform:
+                                      detach=detach_camera, selected=selected)
+        # deformation (main.py:531-539, 586-609): per-frame embeddings when optimize_deform, else the
+        # encoder's prediction; delta = 0 when drop_deform
+        deforms = None
+        if o.optimize_deform:
             flag = batch["mirror_flag"][:, None, None].float()
             d0 = self.deform_emb(batch["frames_idx"]).reshape(-1, o.num_lbs, 3)
             d1 = self.deform_mirror_emb(batch["frames_idx"]).reshape(-1, o.num_lbs, 3)
-            delta = ((1 - flag) * d0 + flag * d1) * o.optimize_deform_lr
+            deforms = ((1 - flag) * d0 + flag * d1) * o.optimize_deform_lr
+        if drop_deform:
+            delta = torch.zeros_like(delta_v_res)
+        elif o.optimize_deform:
+            delta = deforms
         else:
             delta = delta_v_res
         self.solver.refresh()       # lbs / mean shape moved in the last optimiser step: one factorisation
@@ -174,6 +198,12 @@ class MultiframeStep(nn.Module):
             terms["tex_mse"] = mse.mean().detach()
         # hypothesis weighting (main.py:735-746)
         weighted, probs, cam_loss = harness.hypothesis_weighting(total)
+        if selected is not None:                   # probabilities go back to the embeddings they came from (:737-742)
+            with torch.no_grad():
+                fi = batch["frames_idx"]
+                pw = self.prob_embeddings.weight
+                cur = torch.zeros_like(pw[fi]).permute(2, 0, 1)                # [G_all,B,T]
+                pw[fi] = torch.scatter(cur, 0, selected, probs.reshape(G, *fi.shape)).permute(1, 2, 0)
         # priors on the deformed shape (main.py:698-714, 748-751)
         faces_n = self.faces1[None].expand(N * G, -1, -1)
         mesh_3d = Meshes(verts=pred_v, faces=faces_n)
@@ -182,6 +212,16 @@ class MultiframeStep(nn.Module):
         rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
         handle = loss_utils.deform_l2reg(delta_v_res)
         loss = weighted + o.rigid_wt * rigid + o.triangle_reg_wt * triangle + o.handle_deform_reg_wt * handle
+        if predicted_camera is not None:           # main.py:753-762: camera head vs the most probable hypothesis
+            best = probs.reshape(G, N).argmax(dim=0)
+            cam_sel = cam.reshape(G, N, 7)[best, torch.arange(N, device=cam.device)]
+            cam_head = loss_utils.camera_loss(predicted_camera, cam_sel.detach(), 0)
+            loss = loss + o.cam_loss_wt * cam_head
+            terms["cam_loss"] = cam_head.detach()
+        if o.optimize_deform:                      # main.py:763-765: encoder head vs the per-frame deformation embedding
+            deform_loss = torch.nn.functional.mse_loss(delta_v_res, deforms.detach())
+            loss = loss + o.deform_loss_wt * deform_loss
+            terms["deform_loss"] = deform_loss.detach()
         terms.update(mask=mask_loss.mean().detach(), sil_cons=sil_cons.mean().detach(), rigid=rigid.detach(),
                      triangle=triangle.detach(), camera_loss=cam_loss.detach(), probs=probs)
         return loss, terms

@@ -327,6 +327,28 @@ def test_multiframe_step_harness(meshes):
     assert set(["mask", "sil_cons", "rigid", "triangle", "camera_loss", "probs", "tex_mse"]) <= set(terms)
     total2, _ = step(batch, delta, drop_deform=True, detach_camera=True)     # train_utils.py:252's call
     assert torch.isfinite(total2)
+    # hypothesis dropping (main.py:541-570, 737-742; train_utils.py:236-241): only the k most probable
+    # camera embeddings of every frame are rendered, their probabilities are scattered back
+    step.opts.drop_hypothesis = True
+    step.set_num_guesses(2)
+    before = step.prob_embeddings.weight[batch["frames_idx"]].clone()          # [B,T,G] from the warm-up
+    top2 = before.topk(2, dim=-1)[1]
+    step.zero_grad()
+    total3, terms3 = step(batch, delta, textures=tex, imgs=imgs, predicted_camera=torch.randn(N, 7, device=d))
+    total3.backward()
+    assert torch.isfinite(total3) and terms3["probs"].shape == (2, N) and "cam_loss" in terms3
+    after = step.prob_embeddings.weight[batch["frames_idx"]]
+    assert torch.allclose(after.sum(-1), torch.ones(B, T, device=d), atol=1e-5)
+    assert int((after > 0).sum()) <= 2 * N and torch.equal((after > 0) | (after == 0), torch.ones_like(after, dtype=torch.bool))
+    picked = torch.zeros_like(after, dtype=torch.bool).scatter_(-1, top2, True)
+    assert float(after.detach()[~picked].abs().sum()) == 0.0                            # dropped hypotheses carry no probability
+    for g, emb in enumerate(step.cameras):                                     # gradients reach only rendered cameras
+        rows = emb.weight.grad[batch["frames_idx"]].abs().sum(-1) > 0          # [B,T]
+        assert torch.equal(rows, picked[..., g])
+    # deformation embeddings instead of the encoder's offsets (main.py:531-539, 763-765)
+    step.opts.optimize_deform = True
+    total4, terms4 = step(batch, delta)
+    assert torch.isfinite(total4) and "deform_loss" in terms4
 
 
 def test_multiframe_step_hipgraph_matches_eager(meshes):
