@@ -24,6 +24,7 @@ SIGNATURES = {
     "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "acfm_deform_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_deform_apply_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "acfm_correlation_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_of_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_of_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_camera_pipeline": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),

@@ -274,6 +274,26 @@ def of_loss(proj, flows, vis, B, T):
     return _OFLoss.apply(proj, flows, vis, int(B), int(T))
 
 
+# ------------------------------------------------------------------------------ correlation
+def correlation(f1, f2, max_displacement):
+    """Cost volume of MaskFlownet's Correlation layer (pad = max_displacement = md, kernel 1, strides 1):
+    f1, f2 [N,C,H,W] -> [N,(2md+1)^2,H,W].  Forward only (the flow network is frozen in ACFM)."""
+    _lib.require_gpu(f1, f2)
+    if f1.requires_grad or f2.requires_grad:
+        if torch.is_grad_enabled():
+            raise RuntimeError("correlation: forward only (frozen flow network); wrap the call in torch.no_grad()")
+    a, b = _f32c(f1), _f32c(f2)
+    if a.dim() != 4 or a.shape != b.shape:
+        raise ValueError("correlation: two [N,C,H,W] tensors of equal shape, got %s and %s" % (tuple(a.shape), tuple(b.shape)))
+    N, C, H, W = a.shape
+    md = int(max_displacement)
+    out = torch.empty((N, (2 * md + 1) ** 2, H, W), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().acfm_correlation_forward(_lib.ptr(a), _lib.ptr(b), N, C, H, W, md, _lib.ptr(out),
+                                                       _lib.cur_stream(a.device)), "acfm_correlation_forward")
+    return out
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod

@@ -98,6 +98,16 @@ int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, i
 int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
                                int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
 
+/* ---- correlation cost volume (forward only) ----------------------------------------------
+ * replaces correlation_cuda.forward as MaskFlownet calls it (multiframe/data/optical_flow/model/
+ * correlation_package/correlation_cuda_kernel.cu:73-147, correlation.py:20-37; MaskFlownet.py:116,
+ * 416: pad_size = max_displacement = md, kernel_size = 1, stride1 = stride2 = 1, corr_multiply = 1):
+ *   f1, f2 [N,C,H,W] f32 -> out [N,(2md+1)^2,H,W],
+ *   out[n,(tj+md)(2md+1)+(ti+md),y,x] = mean_c f1[n,c,y,x] f2[n,c,y+tj,x+ti]  (zero outside), md in 1..4.
+ * The flow network is frozen in ACFM (flows are precomputed by the optical_flow scripts): no backward. */
+int acfm_correlation_forward(const float* f1, const float* f2, int N, int C, int H, int W, int md, float* out,
+                             void* stream);
+
 /* ---- optical-flow loss -----------------------------------------------------------------
  * replaces the tail of loss_utils.optical_flow_loss (multiframe/nnutils/loss_utils.py:445-474):
  *   proj [B*T,V,3] projected vertices (proj_fn output, x/y in [-1,1]), flows [B*T,H,W,2] GT flow

@@ -524,3 +524,21 @@ def compute_boundaries(masks):
     out[..., 1] = (out[..., 1] / masks.shape[2] - 0.5) * 2
     out = out[..., ::-1].copy()
     return np.concatenate((out, np.array(flag)[:, :, None]), axis=-1).astype(np.float32)
+
+
+def correlation(f1, f2, md):
+    """Cost volume of the reference's correlation extension in MaskFlownet's configuration
+    (correlation_cuda_kernel.cu:73-147 with pad = max_displacement = md, kernel 1, strides 1):
+    out[n, (tj+md)(2md+1)+(ti+md), y, x] = mean_c f1[n,c,y,x] * f2[n,c,y+tj,x+ti], zero outside.
+    Accumulated in float64 (the reference's float32 shuffle-reduction order is not reproduced)."""
+    f1 = np.asarray(f1, np.float64)
+    f2 = np.asarray(f2, np.float64)
+    N, C, H, W = f1.shape
+    D1 = 2 * md + 1
+    pad = np.zeros((N, C, H + 2 * md, W + 2 * md))
+    pad[:, :, md:md + H, md:md + W] = f2
+    out = np.zeros((N, D1 * D1, H, W))
+    for tj in range(-md, md + 1):
+        for ti in range(-md, md + 1):
+            out[:, (tj + md) * D1 + ti + md] = (f1 * pad[:, :, md + tj:md + tj + H, md + ti:md + ti + W]).sum(1) / C
+    return out.astype(np.float32)

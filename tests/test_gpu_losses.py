@@ -483,3 +483,24 @@ def test_optical_flow_loss_fused_vs_torch_path(meshes):
         np.testing.assert_allclose(ca.grad.cpu().numpy(), cb.grad.cpu().numpy(), rtol=1e-3,
                                    atol=1e-4 * float(cb.grad.abs().max()))
         assert float(lb.abs().sum()) > 0
+
+
+def test_correlation_cost_volume_vs_oracle():
+    """the cost volume of the flow network's Correlation layer (the reference's one
+    native extension) in MaskFlownet's configuration, against the fp64 oracle; odd sizes, all md."""
+    from acfm_video_3d_reconstruction_amd.correlation import Correlation
+    d = _d()
+    rng = np.random.default_rng(5)
+    for (N, C, H, W, md) in ((2, 16, 24, 40, 4), (1, 37, 17, 19, 2), (3, 8, 16, 16, 1), (1, 196, 12, 20, 3)):
+        f1 = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        f2 = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        layer = Correlation(pad_size=md, kernel_size=1, max_displacement=md, stride1=1, stride2=1, corr_multiply=1)
+        with torch.no_grad():
+            out = layer(torch.tensor(f1, device=d), torch.tensor(f2, device=d))
+        ref = O.correlation(f1, f2, md)
+        assert out.shape == ref.shape == (N, (2 * md + 1) ** 2, H, W)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+        # the centre channel is the plain channel-mean product
+        np.testing.assert_allclose(out[:, ((2 * md + 1) ** 2) // 2].cpu().numpy(), (f1 * f2).mean(1), rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)

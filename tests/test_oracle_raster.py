@@ -135,3 +135,23 @@ def test_texture_branch_known_answers():
     g = np.ones_like(imgs)
     ga = O.tex_render_backward_atlas(tidx, g, atlas.shape)
     assert abs(ga.sum() - 3 * cov.sum()) < 1e-3
+
+
+def test_oracle_correlation_against_direct_loops():
+    """The correlation oracle (oracle.correlation) against the definition written out with loops
+    (correlation_cuda_kernel.cu:73-147 for pad = md, kernel 1, strides 1)."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    N, C, H, W, md = 1, 3, 5, 6, 2
+    f1, f2 = rng.standard_normal((N, C, H, W)), rng.standard_normal((N, C, H, W))
+    got = O.correlation(f1, f2, md)
+    D1 = 2 * md + 1
+    for tj in range(-md, md + 1):
+        for ti in range(-md, md + 1):
+            for y in range(H):
+                for x in range(W):
+                    s = 0.0
+                    if 0 <= y + tj < H and 0 <= x + ti < W:
+                        s = float((f1[0, :, y, x] * f2[0, :, y + tj, x + ti]).sum()) / C
+                    assert abs(got[0, (tj + md) * D1 + ti + md, y, x] - s) < 1e-6
