@@ -47,14 +47,27 @@ struct RasterWs {
   float* grad_ndc; // [N,V,2]
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
+  int split_slots; // heaviest blocks per XCD group that may be rendered by four workgroups each (raster kernels)
   unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every 32x32-pixel coarse tile (words = ceil(F/64) u64)
   size_t bytes;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+extern int g_split_mode;   // split heuristic: < 0 automatic (acfm_raster.hip), 0 never, 1 always
+
 static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   RasterWs w;
+  {
+    // Splitting costs ~25 % more work per split block (four waves bin and merge).  It pays while a
+    // launch is bound by its few heaviest blocks (one 8x8 block of a dense mesh region runs ~250 us,
+    // the work of a whole frame is ~4 us of the chip): up to ~40 frames at 256^2.  Larger launches
+    // are throughput-bound and keep one wave per block (measured at 64 frames: 312 -> 390 us with it).
+    const int per_group = (N & 7) == 0 ? N / 8 : N;      // meshes per XCD group
+    const size_t blocks = (size_t)N * ((H + 7) / 8) * ((H + 7) / 8);
+    const bool on = g_split_mode < 0 ? blocks <= 40960 : g_split_mode > 0;
+    w.split_slots = !on ? 0 : (per_group * 32 < 1024 ? per_group * 32 : 1024);
+  }
   char* p = (char*)base;
   size_t o = 0;
   w.ndc = (float*)(p + o);      o += align256(sizeof(float) * 3 * (size_t)N * V);

@@ -27,6 +27,8 @@
 
 namespace acfm {
 
+int g_split_mode = -3;   // < 0: automatic, split while longest block > (-mode / 2) x mean work per wave slot; 0 never; 1 always
+
 constexpr int RBLK = 8;       // pixels per block side: one wave64 per block
 constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
 constexpr int RCAP = 128;     // LDS candidate-list capacity of a block (walked early when it could overflow)
@@ -35,6 +37,9 @@ constexpr unsigned long long KEY_NONE = ~0ull;
 constexpr int CNT_TILE = 8;   // cost counters per 8x8 pixels (= per raster block)
 constexpr int SETUP_LDS_TILES = 4096;  // counters kept in LDS up to 1024x1024 images
 constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes near this block
+constexpr int ENTRY_SPLIT = 1 << 29;   // order entry flag: a heavy block, rendered by four workgroups (one per 4x4 pixels)
+constexpr int ENTRY_FLAGS = ENTRY_EMPTY | ENTRY_SPLIT;
+constexpr int SPLIT_MAX_CLASS = 2;     // ... if their cost class is at most this (>= 80 face boxes)
 constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
@@ -220,8 +225,8 @@ __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int
   const int by = bl / blocks, bx = bl % blocks;
   return ws.tile_cnt[((size_t)n * tiles + by * RBLK / CNT_TILE) * tiles + bx * RBLK / CNT_TILE];
 }
-__global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int H) {
-  __shared__ int s_hist[NCLASS], s_base[NCLASS];
+__global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int H, int g_split_dev) {
+  __shared__ int s_hist[NCLASS], s_base[NCLASS], s_split;
   const int G = gridDim.x, g = blockIdx.x, lane = threadIdx.x & 63;
   const int per = (N / G) * tt;
   if (threadIdx.x < NCLASS) s_hist[threadIdx.x] = 0;
@@ -242,8 +247,22 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
   if (threadIdx.x == 0) {
     int acc = 0;
     for (int c = 0; c < NCLASS; ++c) { s_base[c] = acc; acc += s_hist[c]; }
+    // Split the heaviest blocks over four workgroups each?  It adds ~25 % work to those blocks and
+    // shortens the longest one about 3x: worth it while the group's longest block (in candidate
+    // faces ~ walk iterations) outweighs its total work spread over the XCD's 384 wave slots.
+    // Measured crossover: ~16-32 frames at 256^2 (bird 32, horse and cow 16-24).
+    const int mid[NCLASS] = {200, 136, 96, 68, 46, 28, 10, 0};
+    long total = 0;
+    int heaviest = 0;
+    for (int c = NCLASS - 1; c >= 0; --c) {
+      total += (long)s_hist[c] * mid[c];
+      if (s_hist[c] > 0) heaviest = mid[c];
+    }
+    const bool on = g_split_dev < 0 ? 2L * heaviest * 384 > (long)(-g_split_dev) * total : g_split_dev > 0;   // -3: ratio 1.5
+    s_split = (ws.split_slots > 0 && on) ? 1 : 0;
   }
   __syncthreads();
+  const int split_slots = s_split ? ws.split_slots : 0;
   // pass 2: scatter (order inside a class is arbitrary: results never depend on it)
   int* ord = ws.order + (size_t)g * per;
   for (int it = 0; it < iters; ++it) {
@@ -258,7 +277,10 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
       int base = 0;
       if (lane == leader) base = atomicAdd(&s_base[c], __popcll(m));
       base = __shfl(base, leader, 64);
-      if (cls == c) ord[base + __popcll(m & ((1ull << lane) - 1ull))] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0);
+      if (cls == c) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        ord[pos] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0) | ((c <= SPLIT_MAX_CLASS && pos < split_slots) ? ENTRY_SPLIT : 0);
+      }
     }
   }
 }
@@ -266,7 +288,9 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
 // ------------------------------------------------------------------------------- tile skeleton
 struct Tile {
   int n, tid, wv, lane, yi, xi;
-  bool valid, empty;
+  bool valid, empty, none;  // none: nothing to do for this workgroup
+  int sub;                   // >= 0: split role, this wave renders 4x4 pixels (group `sub` of the block) with its four
+                             // 16-lane groups taking every fourth candidate each; -1: the whole 8x8 block
   float xf, yf;
   size_t pix;
   float t_xmin, t_xmax, t_ymin, t_ymax;
@@ -276,40 +300,51 @@ struct Tile {
 // Workgroups are dealt round-robin over the 8 XCDs, so with N % 8 == 0 group g = b % 8 owns the
 // meshes n % 8 == g (one XCD's L2 then holds the records of the meshes it renders).  Pure speed:
 // any mapping gives the same result.
-__device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H) {
+__device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H, bool with_split) {
   Tile t;
   const int tiles = (H + RBLK - 1) / RBLK;
   const int tt = tiles * tiles;
-  const unsigned b = blockIdx.x;
-  int n, tl;
-  if ((N & 7) == 0) {
-    const unsigned g = b & 7u, j = b >> 3;
-    const int eo = ws.order[(size_t)g * ((N >> 3) * tt) + j];
-    const int e = eo & ~ENTRY_EMPTY;
-    t.empty = (eo & ENTRY_EMPTY) != 0;
-    n = (e / tt) * 8 + (int)g;
-    tl = e % tt;
+  const int G = (N & 7) == 0 ? 8 : 1;
+  const int per = (N / G) * tt;
+  const int nsplit = with_split ? G * ws.split_slots * 4 : 0;
+  int b = (int)blockIdx.x;
+  t.none = false;
+  t.sub = -1;
+  int g, j;
+  if (b < nsplit) {          // split role: workgroups 4 slot .. 4 slot + 3 of a group take the four 4x4 groups of entry `slot`
+    g = G == 8 ? (b & 7) : 0;
+    const int q = G == 8 ? (b >> 3) : b;
+    j = q >> 2;
+    t.sub = q & 3;
+    if (j >= per) { t.none = true; j = 0; }
   } else {
-    const int eo = ws.order[b];
-    const int e = eo & ~ENTRY_EMPTY;
-    t.empty = (eo & ENTRY_EMPTY) != 0;
-    n = e / tt;
-    tl = e % tt;
+    b -= nsplit;
+    g = G == 8 ? (b & 7) : 0;
+    j = G == 8 ? (b >> 3) : b;
   }
+  const int eo = ws.order[(size_t)g * per + j];
+  if (t.sub >= 0 && !(eo & ENTRY_SPLIT)) t.none = true;
+  if (t.sub < 0 && with_split && (eo & ENTRY_SPLIT)) t.none = true;   // rendered by its four split workgroups
+  const int e = eo & ~ENTRY_FLAGS;
+  t.empty = (eo & ENTRY_EMPTY) != 0;
+  const int n = (e / tt) * G + g, tl = e % tt;
   t.n = n;
   t.tid = threadIdx.x; t.wv = 0; t.lane = t.tid & 63;
   const int ty = tl / tiles, tx = tl % tiles;
-  // the 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row)
-  const int grp = t.lane >> 4, j = t.lane & 15;
-  t.yi = ty * RBLK + (grp >> 1) * 4 + (j >> 2);
-  t.xi = tx * RBLK + (grp & 1) * 4 + (j & 3);
+  // the 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row); split role: all four
+  // 16-lane groups hold the same 4x4 pixels
+  const int grp = t.sub >= 0 ? t.sub : (t.lane >> 4), jj = t.lane & 15;
+  t.yi = ty * RBLK + (grp >> 1) * 4 + (jj >> 2);
+  t.xi = tx * RBLK + (grp & 1) * 4 + (jj & 3);
   t.valid = (t.yi < H) && (t.xi < H);
   t.yf = pix_to_ndc(H - 1 - t.yi, H);
   t.xf = pix_to_ndc(H - 1 - t.xi, H);
   t.pix = ((size_t)n * H + t.yi) * H + t.xi;
-  // block extent in NDC (pixel centres; x/y decrease with the pixel index)
-  t.t_xmax = pix_to_ndc(H - 1 - tx * RBLK, H); t.t_xmin = pix_to_ndc(H - 1 - (tx * RBLK + RBLK - 1), H);
-  t.t_ymax = pix_to_ndc(H - 1 - ty * RBLK, H); t.t_ymin = pix_to_ndc(H - 1 - (ty * RBLK + RBLK - 1), H);
+  // extent of the block (split role: of the 4x4 group) in NDC (pixel centres; x/y decrease with the pixel index)
+  const int ex0 = tx * RBLK + (t.sub >= 0 ? (t.sub & 1) * 4 : 0), ey0 = ty * RBLK + (t.sub >= 0 ? (t.sub >> 1) * 4 : 0);
+  const int ext = t.sub >= 0 ? 3 : RBLK - 1;
+  t.t_xmax = pix_to_ndc(H - 1 - ex0, H); t.t_xmin = pix_to_ndc(H - 1 - (ex0 + ext), H);
+  t.t_ymax = pix_to_ndc(H - 1 - ey0, H); t.t_ymin = pix_to_ndc(H - 1 - (ey0 + ext), H);
   return t;
 }
 
@@ -385,7 +420,12 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   unsigned short* sub0 = L.sub[0];
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-  if constexpr (!EDGE_CULL) {
+  const bool split = t.sub >= 0;
+  if (split) {
+    // split role: the list was binned against this 4x4 group already; 16-lane group s takes the
+    // candidates s, s+4, s+8, ... (no sub-lists)
+    n0 = (list_n + 3) >> 2; n1 = (list_n + 2) >> 2; n2 = (list_n + 1) >> 2; n3 = list_n >> 2;
+  } else if constexpr (!EDGE_CULL) {
     // one pass: lane i tests candidate i's box against the four 4x4 blocks
     for (int base = 0; base < list_n; base += 64) {
       const int c = base + t.lane;
@@ -460,7 +500,8 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   // iteration ahead was measured: +16 VGPRs, no change in time.)
   const int last = max(my_n - 1, 0);
   for (int i = 0; i < n_max; ++i) {
-    const Cand cur = load_cand(L, my_n > 0 ? sub[min(i, last)] : 0);
+    const int li = min(i, last);
+    const Cand cur = load_cand(L, my_n > 0 ? (split ? 4 * li + grp : (int)sub[li]) : 0);
     const bool have = i < my_n;
     const bool in_box = have &&
         !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
@@ -692,7 +733,8 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
   __shared__ __attribute__((aligned(16))) FwdLds S;
   CandList& L = S.L;
   int* s_fl = S.fl;
-  const Tile t = make_tile(ws, N, H);
+  const Tile t = make_tile(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
+  if (t.none) return;
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
   struct Stamp {
@@ -802,7 +844,29 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
       });
       seen += list_n;
     });
-    if (t.valid) {
+    const bool split = t.sub >= 0;
+    if (split) {
+      // The four 16-lane groups hold the K nearest of their quarter of the candidates for the same
+      // 16 pixels.  Merge: group 0 takes group 1's entries and group 2 takes group 3's, then group 0
+      // takes group 2's; an entry enters by the same bubble insertion (the K nearest of a union are
+      // the K nearest of the two K-nearest lists).  Senders keep their lists untouched while they
+      // are being read; lists are sorted, so a round ends at the first empty slot of every sender.
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        const int mask = round == 0 ? 16 : 32;
+        const bool recv = round == 0 ? ((t.lane & 16) == 0) : ((t.lane & 48) == 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(key[k] & 0xffffffffull), mask, 64);
+          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key[k] >> 32), mask, 64);
+          float oq = __shfl_xor(q[k], mask, 64);
+          unsigned long long ok = recv ? (((unsigned long long)hi << 32) | lo) : KEY_NONE;
+          if (__ballot(ok != KEY_NONE) != 0ull) bubble_insert<K, 0>(key, q, ok, oq, K);
+        }
+      }
+    }
+    const bool out_valid = t.valid && (!split || t.lane < 16);
+    if (out_valid) {
       float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
 #pragma unroll
       for (int k = 0; k < K; ++k) alpha = alpha * q[k];
@@ -817,7 +881,8 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
     if (out.kout == 1) return;
     typedef long long ll2 __attribute__((ext_vector_type(2)));  // K even -> 16-byte pieces
     constexpr int CH = K / 2;                                   // pieces per pixel
-    if constexpr (sizeof(FwdLds) >= (size_t)64 * K * 8) {
+    constexpr bool STAGED = sizeof(FwdLds) >= (size_t)64 * K * 8;
+    if (STAGED && !split) {
       // The K ids of a pixel are 8K contiguous bytes, so a lane storing its own row hits 64
       // different cache lines per instruction.  The block's ids are therefore staged in LDS (the
       // candidate lists are dead by now) in image order -- 8 rows of 64K contiguous bytes -- and
@@ -842,7 +907,7 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
           reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
       }
     } else {
-      if (!t.valid) return;
+      if (!out_valid) return;
       ll2* o2 = reinterpret_cast<ll2*>(out.p2f + t.pix * K);
 #pragma unroll
       for (int k2 = 0; k2 < CH; ++k2) {
@@ -899,7 +964,8 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
   // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
   // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
   __shared__ float s_acc[RCAP][6];
-  const Tile t = make_tile(ws, N, H);
+  const Tile t = make_tile(ws, N, H, true);
+  if (t.none) return;
 
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
@@ -1119,7 +1185,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws);
-  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H);
+  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, g_split_mode);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -1130,16 +1196,17 @@ static bool bad_dims(int N, int V, int F, int H) {
          (size_t)N * ((H + RBLK - 1) / RBLK) * ((H + RBLK - 1) / RBLK) > 0x7fffffffull;
 }
 
-static unsigned tile_grid(int N, int H) {
+static unsigned tile_grid(int N, int H, int split_slots = 0) {
   const int tiles = (H + RBLK - 1) / RBLK;
-  return (unsigned)((size_t)tiles * tiles * N);
+  const size_t G = (N & 7) == 0 ? 8 : 1;
+  return (unsigned)((size_t)tiles * tiles * N + G * (size_t)split_slots * 4);
 }
 
 template <int K>
 static int launch_sil_fwd(const RasterWs& ws, int N, int F, int H, float blur, float sigma,
                           const FwdOut& out, hipStream_t st) {
   ProfScope ps(ACFM_PROF_SIL_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H, ws.split_slots)), dim3(RT), 0, st, ws, N, F,
                      H, blur, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1181,6 +1248,9 @@ int acfm_prof_collect(float* ms_host, int* count_host, int n) {
   g_ev_n = 0;
   return ACFM_OK;
 }
+
+// diagnostic (not in the public header): override the block-splitting heuristic (-1 auto, 0 off, 1 on)
+void acfm_debug_set_split(int mode) { acfm::g_split_mode = mode; }
 
 // diagnostic (not in the public header): resident workgroups per CU of the raster kernels
 int acfm_debug_occupancy(int which, int dyn_lds) {
@@ -1278,7 +1348,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H)), dim3(RT), lds, st, ws, mask,
+    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, ws.split_slots)), dim3(RT), lds, st, ws, mask,
                        reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
                        blur_radius, sigma);
   }

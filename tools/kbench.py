@@ -37,6 +37,8 @@ def main():
     atlas = torch.rand(N, f.shape[0], 6, 6, 3, device=dev, requires_grad=True)
     bds = torch.cat([torch.rand(N, 800, 2, device=dev) * 2 - 1, torch.ones(N, 800, 1, device=dev)], -1)
     lib = _lib.lib()
+    if os.environ.get("ACFM_SPLIT") is not None:
+        ctypes.CDLL(_lib.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
 
     def run():
         if "sil" in a.what:

@@ -17,7 +17,7 @@ cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=dev
 faces = torch.tensor(f, device=dev)[None].repeat(N, 1, 1).contiguous()
 atlas = torch.rand(N, f.shape[0], 6, 6, 3, device=dev)
 raw = ctypes.CDLL(_lib.SO_PATH)
-nb = N * (H // 8) ** 2   # one workgroup (wave) per 8x8 block
+nb = N * (H // 8) ** 2 + (8 if N % 8 == 0 else 1) * min(1024, 32 * (N // 8 if N % 8 == 0 else N)) * 4   # blocks + split slots (upper bound)
 buf = torch.zeros(nb * 3, dtype=torch.int64, device=dev)
 def run():
     if mode == "sil": ops.sil_render(verts, faces, cams, H)
@@ -28,6 +28,8 @@ raw.acfm_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 run(); torch.cuda.synchronize()
 raw.acfm_debug_set_stamp_buffer(None)
 b = buf.cpu().numpy().reshape(nb, 3)
+b = b[b[:, 0] != 0]          # unused split slots leave no stamp
+nb = len(b)
 t0, t1, hw = b[:, 0], b[:, 1], b[:, 2]
 dur = (t1 - t0) / 100.0  # us
 span = (t1.max() - t0.min()) / 100.0
