@@ -186,3 +186,26 @@ def test_texture_and_flow_on_quadruped_clip(meshes):
     ri, rs, rp2, _ = O.tex_render(verts, f, cams, atlas, H)
     np.testing.assert_array_equal(p2f.cpu().numpy(), rp2)
     np.testing.assert_allclose(imgs.cpu().numpy(), ri, atol=1e-6)
+
+
+def test_split_and_unsplit_heavy_blocks_agree(meshes):
+    """The heaviest blocks of a small launch are rendered by four workgroups each (candidate-parallel,
+    merged K-nearest lists); forced on and forced off both reproduce the oracle: pix_to_face bit for
+    bit, mask and gradients within tolerance."""
+    import ctypes
+    from acfm_video_3d_reconstruction_amd import _lib
+    from acfm_video_3d_reconstruction_amd.synthetic import batch_verts, make_cams
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    rng = np.random.default_rng(77)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    n, H = 3, 96
+    verts = batch_verts(v, n, rng, 0.005)
+    cams = make_cams(n, rng, extent=float(np.abs(v).max()))
+    cams[:, 0] *= 0.35                                     # a small bird: > 80 face boxes on its blocks
+    try:
+        for mode in (1, 0):
+            raw.acfm_debug_set_split(mode)
+            _check_sil(verts, f, cams, H, seed=mode)
+            _check_sil(verts, f, cams, H, K=4, seed=mode)
+    finally:
+        raw.acfm_debug_set_split(-3)
