@@ -65,7 +65,6 @@ def edt_and_boundaries(gt_mask):
 
 def main():
     if os.environ.get("ACFM_SPLIT") is not None:   # diagnostic: block-splitting heuristic off / on
-        import ctypes
         from acfm_video_3d_reconstruction_amd import _lib as _l
         ctypes.CDLL(_l.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
     a = parse()
