@@ -94,6 +94,22 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// x / y for normal-range y: refined reciprocal, quotient, two residual corrections -- the
+// correctly rounded result of the IEEE division sequence without its scaling / fix-up steps (8
+// instead of ~11 instructions; callers with several numerators over one denominator share r).
+// Used where the operands cannot be denormal or overflow (areas, squared edge lengths > 1e-8 and
+// coordinates of order 1); checked bit for bit against the oracle's C divisions by the parity tests.
+__device__ __forceinline__ float recip_refined(float y) {
+  const float r0 = __builtin_amdgcn_rcpf(y);
+  return __builtin_fmaf(__builtin_fmaf(-y, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_by(float x, float y, float r) {
+  float q = x * r;
+  q = __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+  q = __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+  return q;
+}
+
 // PointLineDistanceForward: squared distance from p to segment ab.
 __device__ __forceinline__ float point_line_dist(float px, float py, float ax, float ay, float bx,
                                                  float by) {
@@ -103,7 +119,7 @@ __device__ __forceinline__ float point_line_dist(float px, float py, float ax, f
     const float dx = px - bx, dy = py - by;
     return dx * dx + dy * dy;
   }
-  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  float t = div_by(bax * (px - ax) + bay * (py - ay), l2, recip_refined(l2));
   t = fminf(fmaxf(t, 0.0f), 1.0f);
   const float qx = ax + t * bax, qy = ay + t * bay;
   const float dx = qx - px, dy = qy - py;

@@ -626,16 +626,20 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
   const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
   const float z0 = B.z, z1 = B.w;
   const float denom = area + ACFM_K_EPS;
-  const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / denom;
-  const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / denom;
-  const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / denom;
+  // three IEEE divisions by the same denominator share one refined reciprocal (acfm_common.h)
+  const float r = recip_refined(denom);
+  auto div = [&](float x) { return div_by(x, denom, r); };
+  const float w0 = div(edge_fn(xf, yf, x1, y1, x2, y2));
+  const float w1 = div(edge_fn(xf, yf, x2, y2, x0, y0));
+  const float w2 = div(edge_fn(xf, yf, x0, y0, x1, y1));
   float c0 = w0, c1 = w1, c2 = w2;
   if (CLIP) {
     c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
     c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
     c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
     const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-    c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
+    const float rs = recip_refined(s);
+    c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
   }
   const float pz = c0 * z0 + c1 * z1 + c2 * z2;
   inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
@@ -945,7 +949,7 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
     gbx = -2.0f * (px - bx) * g; gby = -2.0f * (py - by) * g;
     return;
   }
-  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  float t = div_by(bax * (px - ax) + bay * (py - ay), l2, recip_refined(l2));
   t = fminf(fmaxf(t, 0.0f), 1.0f);
   const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
   const float ex = 2.0f * (qx - px), ey = 2.0f * (qy - py);
