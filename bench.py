@@ -235,6 +235,9 @@ def main():
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
+        if traffic:   # what the kernel actually moves (the API's K int64 ids per pixel dominate): context, not `achieved`
+            moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1 only)
     cpu = None
