@@ -49,3 +49,12 @@ for x in range(8):
               "idle-weighted util %.2f" % (dur[sel].sum() / (384 * (t1[sel].max() - t0[sel].min()) / 100.0)))
 order = np.argsort(-dur)[:8]
 print("heaviest blocks:", [(int(i), round(float(dur[i]), 1), round(float(start[i]), 1)) for i in order])
+
+# occupancy timeline: running workgroups (time-averaged) and starts per 20-us bin
+edges = np.arange(0, span + 20, 20.0)
+s0, s1 = (t0 - t0.min()) / 100.0, (t1 - t0.min()) / 100.0
+print("bin_us  running(avg)  starts  mean_dur_of_starts")
+for a_, b_ in zip(edges[:-1], edges[1:]):
+    ov = np.clip(np.minimum(s1, b_) - np.maximum(s0, a_), 0, None).sum() / (b_ - a_)
+    st = (s0 >= a_) & (s0 < b_)
+    print("%6.0f  %10.0f  %7d  %8.1f" % (a_, ov, st.sum(), dur[st].mean() if st.any() else 0))
