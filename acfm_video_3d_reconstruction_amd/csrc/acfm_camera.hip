@@ -109,6 +109,41 @@ __global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __res
   for (int k = 0; k < 7; ++k) gemb[(size_t)r * 7 + k] = ge[k];
 }
 
+// cam = (s, tx, ty, q / max(|q|, 1e-12)): the camera the refinement loop renders with while it
+// optimises scale, translation and an unnormalised quaternion (predictor.py:301-308:
+// torch.cat([scale, trans, F.normalize(quat)])); one thread per camera, forward and backward
+__global__ void k_camera_normalize(const float* __restrict__ raw, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* e = raw + (size_t)n * 7;
+  const float nrm = sqrtf(e[3] * e[3] + e[4] * e[4] + e[5] * e[5] + e[6] * e[6]);
+  const float d = fmaxf(nrm, 1e-12f);
+  float* o = out + (size_t)n * 7;
+  o[0] = e[0]; o[1] = e[1]; o[2] = e[2];
+#pragma unroll
+  for (int k = 3; k < 7; ++k) o[k] = e[k] / d;
+}
+
+__global__ void k_camera_normalize_bwd(const float* __restrict__ raw, const float* __restrict__ gout, int N,
+                                       float* __restrict__ graw) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* e = raw + (size_t)n * 7;
+  const float* g = gout + (size_t)n * 7;
+  float* o = graw + (size_t)n * 7;
+  o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+  const float nrm = sqrtf(e[3] * e[3] + e[4] * e[4] + e[5] * e[5] + e[6] * e[6]);
+  if (nrm > 1e-12f) {
+    const float q0 = e[3] / nrm, q1 = e[4] / nrm, q2 = e[5] / nrm, q3 = e[6] / nrm;
+    const float dot = q0 * g[3] + q1 * g[4] + q2 * g[5] + q3 * g[6];
+    o[3] = (g[3] - q0 * dot) / nrm; o[4] = (g[4] - q1 * dot) / nrm;
+    o[5] = (g[5] - q2 * dot) / nrm; o[6] = (g[6] - q3 * dot) / nrm;
+  } else {
+#pragma unroll
+    for (int k = 3; k < 7; ++k) o[k] = g[k] / 1e-12f;
+  }
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -131,6 +166,22 @@ int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, 
     return ACFM_E_BADARG;
   hipLaunchKernelGGL(k_camera_bwd, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, emb, mirror_flag,
                      transforms, grad_cams, R, N, scale_lr_decay, grad_emb);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_normalize(const float* cam_raw, int N, float* cams, void* stream) {
+  if (!cam_raw || !cams || N <= 0) return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_camera_normalize, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, cam_raw, N, cams);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_normalize_backward(const float* cam_raw, const float* grad_cams, int N, float* grad_raw,
+                                   void* stream) {
+  if (!cam_raw || !grad_cams || !grad_raw || N <= 0) return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_camera_normalize_bwd, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, cam_raw,
+                     grad_cams, N, grad_raw);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -233,6 +233,36 @@ def camera_pipeline(cam_emb, mirror_flag, transforms, scale_lr_decay=1.0):
     return _CameraPipeline.apply(cam_emb, mirror_flag, transforms, scale_lr_decay)
 
 
+class _CameraNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw):
+        _lib.require_gpu(raw)
+        r = _f32c(raw)
+        N = r.numel() // 7
+        out = torch.empty_like(r)
+        with torch.cuda.device(r.device):
+            _lib.check(_lib.lib().acfm_camera_normalize(_lib.ptr(r), N, _lib.ptr(out), _lib.cur_stream(r.device)),
+                       "acfm_camera_normalize")
+        ctx.save_for_backward(r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (r,) = ctx.saved_tensors
+        g = _f32c(g)
+        gr = torch.empty_like(r)
+        with torch.cuda.device(r.device):
+            _lib.check(_lib.lib().acfm_camera_normalize_backward(_lib.ptr(r), _lib.ptr(g), r.numel() // 7, _lib.ptr(gr),
+                                                                 _lib.cur_stream(r.device)),
+                       "acfm_camera_normalize_backward")
+        return gr
+
+
+def camera_normalize(cam_raw):
+    """[N,7] (s, tx, ty, q) -> (s, tx, ty, q/|q|): torch.cat([scale, trans, F.normalize(quat)]) in one kernel."""
+    return _CameraNormalize.apply(cam_raw)
+
+
 # ------------------------------------------------------------------------------ optical flow
 class _OFLoss(torch.autograd.Function):
     @staticmethod

@@ -24,12 +24,15 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
     Returns (pred_v, cam, delta, history of total losses)."""
     delta = delta_v_res.clone().detach().requires_grad_(True)
     params = [delta]
-    scale, trans, quat = cam_pred[:, :1], cam_pred[:, 1:3], cam_pred[:, 3:]
     if optimize_camera:
-        scale, trans, quat = (x.clone().detach().requires_grad_(True) for x in (scale, trans, quat))
-        params += [scale, trans, quat]
+        # the reference optimises scale, trans and quat as three tensors (predictor.py:296-300); Adam is
+        # element-wise, so one [N,7] leaf is the same optimisation with a third of the launches
+        cam_raw = cam_pred.clone().detach().requires_grad_(True)
+        params.append(cam_raw)
     graphable = use_graph and delta.is_cuda
-    opt = torch.optim.Adam(params, lr=lr, capturable=graphable)
+    # one fused multi-tensor kernel per step instead of ~a dozen foreach launches (the loop is
+    # launch-latency-bound: ~30 short kernels of this library per iteration)
+    opt = torch.optim.Adam(params, lr=lr, capturable=graphable, fused=bool(delta.is_cuda))
     state = {"cam": cam_pred.detach(), "pred_v": None}
     hist_buf = torch.zeros(max(num_optim_iter, 1), device=delta.device)
     it_idx = torch.zeros((), dtype=torch.long, device=delta.device)
@@ -37,17 +40,21 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
     def iteration():
         cam = state["cam"]
         if optimize_camera:
-            cam = torch.cat([scale, trans, torch.nn.functional.normalize(quat, dim=-1)], dim=1)
+            if cam_raw.is_cuda:
+                from . import ops
+                cam = ops.camera_normalize(cam_raw)
+            else:
+                cam = torch.cat([cam_raw[:, :3], torch.nn.functional.normalize(cam_raw[:, 3:], dim=-1)], dim=1)
         pred_v = solver(delta)                                                    # predictor.py:310-315
         mask_pred, pix_to_face = renderer(pred_v, faces, cam)                     # :317
         l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
-        mask_loss = l1.mean()                                                     # :318 (reduce=True)
         pred_proj = renderer.project_points(pred_v, cam)                          # :319
-        edt_loss = edt.mean()                                                     # :320
         bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
-        # the reference pairs bdt_reg_wt with the EDT term and edt_reg_wt with the boundary term (:322)
-        sil_cons = bdt_reg_wt * edt_loss + edt_reg_wt * bdt_loss
-        total = mask_loss_wt * mask_loss + boundaries_reg_wt * sil_cons           # :343-344
+        # mask_loss = l1.mean() (:318), edt_loss = edt.mean() (:320); the reference pairs bdt_reg_wt with
+        # the EDT term and edt_reg_wt with the boundary term (:322); total as at :343-344, with the two
+        # per-frame means folded into one
+        per_frame = mask_loss_wt * l1 + (boundaries_reg_wt * bdt_reg_wt) * edt
+        total = per_frame.mean() + (boundaries_reg_wt * edt_reg_wt) * bdt_loss
         if of_loss_wt > 0 and optical_flows is not None:
             b = optical_flows.shape[0]
             masks_of = masks.reshape(b, num_frames, masks.shape[1], masks.shape[2])

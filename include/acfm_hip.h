@@ -135,6 +135,12 @@ int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, 
                                   const float* grad_cams, int R, int N, float scale_lr_decay, float* grad_emb,
                                   void* stream);
 
+/* cam = (s, tx, ty, q / max(|q|, 1e-12)) of a raw [N,7] camera parameter: the per-iteration
+ * torch.cat([scale, trans, F.normalize(quat)]) of the refinement loop (nnutils/predictor.py:301-308). */
+int acfm_camera_normalize(const float* cam_raw, int N, float* cams, void* stream);
+int acfm_camera_normalize_backward(const float* cam_raw, const float* grad_cams, int N, float* grad_raw,
+                                   void* stream);
+
 /* ---- template deformation solve ------------------------------------------------------
  * replaces the per-frame torch.cholesky / torch.cholesky_solve of multiframe/main.py:586-609
  * (also optimization/main.py:474-496, nnutils/predictor.py:260-276): with A = softmax(lbs, dim 0)^T

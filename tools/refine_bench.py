@@ -35,3 +35,14 @@ for mode in (False, True, False, True):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("graph=%-5s %d iterations x %d frames: %.1f ms total, %.3f ms/iter, %.0f frame-iters/s, loss %.5f -> %.5f" % (
         mode, a.iters, N, 1e3 * dt, 1e3 * dt / a.iters, N * a.iters / dt, hist[0], hist[-1]))
+# per-kernel breakdown of one eager iteration (hipEvent brackets of the library's own kernels)
+from acfm_video_3d_reconstruction_amd import _lib
+lib = _lib.lib(); lib.acfm_prof_enable(1)
+refine_clip(r, solver, torch.zeros(N, Kh, 3, device=d), cams, faces, gt, edt, bds, num_optim_iter=a.iters,
+            optimize_camera=True, use_graph=False)
+torch.cuda.synchronize()
+prof = _lib.prof_collect(); lib.acfm_prof_enable(0)
+tot = 0.0
+for k, (ms, c) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+    print("   %-24s %8.1f us/iter  x%.1f" % (k, 1e3 * ms / a.iters, c / a.iters)); tot += 1e3 * ms / a.iters
+print("   library kernels total %.1f us/iter" % tot)

@@ -34,7 +34,7 @@ tex = torch.rand(N, f.shape[0], 6, 6, 3, device=d, requires_grad=True) if a.tex 
 imgs = torch.rand(N, 3, H, H, device=d) if a.tex else None
 if a.graph:
     from acfm_video_3d_reconstruction_amd.graphed import GraphedStep
-    opt = torch.optim.Adam(list(step.parameters()), lr=1e-4, capturable=True)
+    opt = torch.optim.Adam(list(step.parameters()), lr=1e-4, capturable=True, fused=True)
     inputs = dict(batch, delta=delta.detach())
     if a.tex: inputs.update(tex=tex.detach(), imgs=imgs)
     runner = GraphedStep(lambda i: step(i, i["delta"], textures=i.get("tex"), imgs=i.get("imgs"))[0], opt, inputs,
@@ -42,7 +42,7 @@ if a.graph:
     def one():
         runner(inputs)
 else:
-    opt = torch.optim.Adam(list(step.parameters()) + [delta] + ([tex] if a.tex else []), lr=1e-4)
+    opt = torch.optim.Adam(list(step.parameters()) + [delta] + ([tex] if a.tex else []), lr=1e-4, fused=True)
     def one():
         opt.zero_grad(set_to_none=True)
         loss, _ = step(batch, delta, textures=tex, imgs=imgs)
