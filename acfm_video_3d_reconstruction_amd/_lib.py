@@ -46,10 +46,10 @@ SIGNATURES = {
     "acfm_vertex_color_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
                                        _i, _f, _vp]),
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_cot_laplacian": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "acfm_laplacian_smoothing_state_floats": (_sz, [_i, _i]),
     "acfm_laplacian_smoothing": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -60,8 +60,8 @@ SIGNATURES = {
     "acfm_edt": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "acfm_boundaries": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_visible_vertices": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "acfm_bds_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "acfm_bds_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_bds_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_bds_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _ERR = {1: "ACFM_E_BADARG (shape/parameter outside what the kernels support)",

@@ -10,13 +10,15 @@ constexpr int LTPB = 256;
 constexpr int PIX_PER_BLOCK = 4096;  // 16 px per thread: 4 x float4
 
 // out[n] += (sum|m-gt|/HW, sum m*gt, sum(m+gt-m*gt), sum edt*m/HW); one pass over the mask.
+// (prediction n is compared with reference n % RB: the G camera hypotheses of a frame share the
+// frame's ground truth, so the trainer's gt.repeat(G, ...) copies are never made)
 __global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ mask,
                                                       const float* __restrict__ gt,
-                                                      const float* __restrict__ edt, int HW,
+                                                      const float* __restrict__ edt, int HW, int RB,
                                                       float* __restrict__ out) {
   __shared__ float s_red[4][4];
   const int n = blockIdx.y, tid = threadIdx.x;
-  const size_t base = (size_t)n * HW;
+  const size_t base = (size_t)n * HW, rbase = (size_t)(n % RB) * HW;
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -25,8 +27,8 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ 
     for (int i = start + tid * 4; i < end; i += LTPB * 4) {
       const float4 m = *reinterpret_cast<const float4*>(mask + base + i);
       float4 g = make_float4(0, 0, 0, 0), e = make_float4(0, 0, 0, 0);
-      if (gt) g = *reinterpret_cast<const float4*>(gt + base + i);
-      if (edt) e = *reinterpret_cast<const float4*>(edt + base + i);
+      if (gt) g = *reinterpret_cast<const float4*>(gt + rbase + i);
+      if (edt) e = *reinterpret_cast<const float4*>(edt + rbase + i);
       a0 += fabsf(m.x - g.x) + fabsf(m.y - g.y) + fabsf(m.z - g.z) + fabsf(m.w - g.w);
       a1 += m.x * g.x + m.y * g.y + m.z * g.z + m.w * g.w;
       a2 += (m.x + g.x - m.x * g.x) + (m.y + g.y - m.y * g.y) + (m.z + g.z - m.z * g.z) +
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ 
     }
   } else {
     for (int i = start + tid; i < end; i += LTPB) {
-      const float m = mask[base + i], g = gt ? gt[base + i] : 0.f, e = edt ? edt[base + i] : 0.f;
+      const float m = mask[base + i], g = gt ? gt[rbase + i] : 0.f, e = edt ? edt[rbase + i] : 0.f;
       a0 += fabsf(m - g); a1 += m * g; a2 += m + g - m * g; a3 += e * m;
     }
   }
@@ -54,16 +56,16 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ 
 __global__ __launch_bounds__(LTPB) void k_mask_losses_bwd(const float* __restrict__ mask,
                                                           const float* __restrict__ gt,
                                                           const float* __restrict__ edt,
-                                                          const float* __restrict__ go, int HW,
+                                                          const float* __restrict__ go, int HW, int RB,
                                                           float* __restrict__ grad_mask) {
   const int n = blockIdx.y;
-  const size_t base = (size_t)n * HW;
+  const size_t base = (size_t)n * HW, rbase = (size_t)(n % RB) * HW;
   const float inv = 1.0f / (float)HW;
   const float g0 = go[4 * n] * inv, g1 = go[4 * n + 1], g2 = go[4 * n + 2], g3 = go[4 * n + 3] * inv;
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
   for (int i = start + threadIdx.x; i < end; i += LTPB) {
-    const float m = mask[base + i], g = gt ? gt[base + i] : 0.f, e = edt ? edt[base + i] : 0.f;
+    const float m = mask[base + i], g = gt ? gt[rbase + i] : 0.f, e = edt ? edt[rbase + i] : 0.f;
     const float df = m - g;
     const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
     grad_mask[base + i] = g0 * sgn + g1 * g + g2 * (1.0f - g) + g3 * e;
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses_bwd(const float* __restric
 // (tex*m - img*m)^2; out[n] accumulated with one atomic per block.
 __global__ __launch_bounds__(LTPB) void k_tex_mse(const float* __restrict__ tex,
                                                   const float* __restrict__ img,
-                                                  const float* __restrict__ m, int HW,
+                                                  const float* __restrict__ m, int HW, int RB,
                                                   float* __restrict__ out) {
   __shared__ float s_red[4];
   const int n = blockIdx.y, tid = threadIdx.x;
-  const size_t b3 = (size_t)n * 3 * HW, b1 = (size_t)n * HW;
+  const size_t b3 = (size_t)n * 3 * HW, r3 = (size_t)(n % RB) * 3 * HW, b1 = (size_t)(n % RB) * HW;
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
   float acc = 0.f;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(LTPB) void k_tex_mse(const float* __restrict__ tex,
     const float mk = m[b1 + i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float d = tex[b3 + (size_t)c * HW + i] * mk - img[b3 + (size_t)c * HW + i] * mk;
+      const float d = tex[b3 + (size_t)c * HW + i] * mk - img[r3 + (size_t)c * HW + i] * mk;
       acc += d * d;
     }
   }
@@ -99,10 +101,10 @@ __global__ __launch_bounds__(LTPB) void k_tex_mse(const float* __restrict__ tex,
 __global__ __launch_bounds__(LTPB) void k_tex_mse_bwd(const float* __restrict__ tex,
                                                       const float* __restrict__ img,
                                                       const float* __restrict__ m,
-                                                      const float* __restrict__ go, int HW,
+                                                      const float* __restrict__ go, int HW, int RB,
                                                       float* __restrict__ gtex) {
   const int n = blockIdx.y;
-  const size_t b3 = (size_t)n * 3 * HW, b1 = (size_t)n * HW;
+  const size_t b3 = (size_t)n * 3 * HW, r3 = (size_t)(n % RB) * 3 * HW, b1 = (size_t)(n % RB) * HW;
   const float w = go[n] * 2.0f / (3.0f * (float)HW);
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(LTPB) void k_tex_mse_bwd(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const size_t o = b3 + (size_t)c * HW + i;
-      gtex[o] = w * (tex[o] * mk - img[o] * mk) * mk;
+      gtex[o] = w * (tex[o] * mk - img[r3 + (size_t)c * HW + i] * mk) * mk;
     }
   }
 }
@@ -135,7 +137,7 @@ __global__ void k_visible(const int64_t* __restrict__ p2f, const int64_t* __rest
 
 __global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ verts_xy,
                                                    const float* __restrict__ bds,
-                                                   const uint8_t* __restrict__ vis, int V, int P,
+                                                   const uint8_t* __restrict__ vis, int V, int P, int RB,
                                                    float* __restrict__ loss, int32_t* __restrict__ argmin) {
   extern __shared__ float s_xy[];  // [V][2], x = +inf for invisible verts
   __shared__ float s_red[4];
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ ver
   const int p = blockIdx.x * LTPB + tid;
   float contrib = 0.f;
   if (p < P) {
-    const float* b = bds + ((size_t)n * P + p) * 3;
+    const float* b = bds + ((size_t)(n % RB) * P + p) * 3;
     const float bx = b[0], by = b[1], bm = b[2];
     float best = 1000.0f;  // loss_utils.py:228: invisible vertices sit at distance 1000
     int bi = -1;
@@ -169,13 +171,13 @@ __global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ ver
 
 __global__ void k_bds_loss_bwd(const float* __restrict__ verts_xy, const float* __restrict__ bds,
                                const int32_t* __restrict__ argmin, const float* __restrict__ gl, int V,
-                               int P, float* __restrict__ gv) {
+                               int P, int RB, float* __restrict__ gv) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int v = argmin[(size_t)n * P + p];
   if (v < 0) return;
-  const float* b = bds + ((size_t)n * P + p) * 3;
+  const float* b = bds + ((size_t)(n % RB) * P + p) * 3;
   const float g = gl[n] * b[2];
   if (g == 0.f) return;
   const float* x = verts_xy + ((size_t)n * V + v) * 2;
@@ -256,49 +258,53 @@ using namespace acfm;
 
 extern "C" {
 
-int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW, float* out,
-                     void* stream) {
-  if (!mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW, int ref_batch,
+                     float* out, void* stream) {
+  if (!mask || !out || N <= 0 || N > 65535 || HW <= 0 || ref_batch <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(out, sizeof(float) * 4 * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   const int chunks = (HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
   ProfScope ps(ACFM_PROF_MASK_LOSS, st);
-  hipLaunchKernelGGL(k_mask_losses, dim3(chunks, N), dim3(LTPB), 0, st, mask, gt, edt, HW, out);
+  hipLaunchKernelGGL(k_mask_losses, dim3(chunks, N), dim3(LTPB), 0, st, mask, gt, edt, HW, ref_batch, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
 
 int acfm_mask_losses_backward(const float* mask, const float* gt, const float* edt,
-                              const float* grad_out, int N, int HW, float* grad_mask, void* stream) {
-  if (!mask || !grad_out || !grad_mask || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+                              const float* grad_out, int N, int HW, int ref_batch, float* grad_mask,
+                              void* stream) {
+  if (!mask || !grad_out || !grad_mask || N <= 0 || N > 65535 || HW <= 0 || ref_batch <= 0 || N % ref_batch != 0)
+    return ACFM_E_BADARG;
   const int chunks = (HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
   ProfScope ps(ACFM_PROF_MASK_LOSS_BWD, (hipStream_t)stream);
   hipLaunchKernelGGL(k_mask_losses_bwd, dim3(chunks, N), dim3(LTPB), 0, (hipStream_t)stream, mask, gt,
-                     edt, grad_out, HW, grad_mask);
+                     edt, grad_out, HW, ref_batch, grad_mask);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
 
-int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, float* out,
-                 void* stream) {
-  if (!tex || !img || !mask || !out || N <= 0 || N > 65535 || HW <= 0) return ACFM_E_BADARG;
+int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, int ref_batch,
+                 float* out, void* stream) {
+  if (!tex || !img || !mask || !out || N <= 0 || N > 65535 || HW <= 0 || ref_batch <= 0 || N % ref_batch != 0)
+    return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(out, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_TEX_MSE, st);
   hipLaunchKernelGGL(k_tex_mse, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st, tex,
-                     img, mask, HW, out);
+                     img, mask, HW, ref_batch, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
 
 int acfm_tex_mse_backward(const float* tex, const float* img, const float* mask, const float* grad_out,
-                          int N, int HW, float* grad_tex, void* stream) {
-  if (!tex || !img || !mask || !grad_out || !grad_tex || N <= 0 || N > 65535 || HW <= 0)
+                          int N, int HW, int ref_batch, float* grad_tex, void* stream) {
+  if (!tex || !img || !mask || !grad_out || !grad_tex || N <= 0 || N > 65535 || HW <= 0 || ref_batch <= 0 ||
+      N % ref_batch != 0)
     return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_TEX_MSE_BWD, st);
   hipLaunchKernelGGL(k_tex_mse_bwd, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st,
-                     tex, img, mask, grad_out, HW, grad_tex);
+                     tex, img, mask, grad_out, HW, ref_batch, grad_tex);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -317,8 +323,9 @@ int acfm_visible_vertices(const int64_t* pix_to_face, const int64_t* faces, int 
 }
 
 int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, int N, int V, int P,
-                  float* loss, int32_t* argmin, void* stream) {
-  if (!verts_xy || !bds || !vis || !loss || !argmin || N <= 0 || N > 65535 || V <= 0 || P <= 0)
+                  int ref_batch, float* loss, int32_t* argmin, void* stream) {
+  if (!verts_xy || !bds || !vis || !loss || !argmin || N <= 0 || N > 65535 || V <= 0 || P <= 0 || ref_batch <= 0 ||
+      N % ref_batch != 0)
     return ACFM_E_BADARG;
   const size_t lds = sizeof(float) * 2 * (size_t)V;
   if (lds > 150 * 1024) return ACFM_E_BADARG;
@@ -326,23 +333,23 @@ int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, i
   if (zero_async(loss, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_BDS, st);
   hipLaunchKernelGGL(k_bds_loss, dim3((P + LTPB - 1) / LTPB, N), dim3(LTPB), lds, st, verts_xy, bds, vis,
-                     V, P, loss, argmin);
+                     V, P, ref_batch, loss, argmin);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
 
 int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_t* argmin,
-                           const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
+                           const float* grad_loss, int N, int V, int P, int ref_batch, float* grad_verts_xy,
                            void* stream) {
   if (!verts_xy || !bds || !argmin || !grad_loss || !grad_verts_xy || N <= 0 || N > 65535 || V <= 0 ||
-      P <= 0)
+      P <= 0 || ref_batch <= 0 || N % ref_batch != 0)
     return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(grad_verts_xy, sizeof(float) * 2 * (size_t)N * V, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_BDS_BWD, st);
   hipLaunchKernelGGL(k_bds_loss_bwd, dim3((P + 255) / 256, N), dim3(256), 0, st, verts_xy, bds, argmin,
-                     grad_loss, V, P, grad_verts_xy);
+                     grad_loss, V, P, ref_batch, grad_verts_xy);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

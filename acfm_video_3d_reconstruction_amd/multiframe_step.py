@@ -100,11 +100,11 @@ class MultiframeStep(nn.Module):
     def _silhouette_terms(self, pred_v, faces, cam, batch, G):
         o = self.opts
         mask_pred, pix_to_face = self.renderer(pred_v, faces, cam)
-        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, batch["masks"].repeat(G, 1, 1),
-                                                        batch["edts_barrier"].repeat(G, 1, 1, 1))
+        # the frame's ground truth is shared by its G hypotheses (the loss kernels index it n % N: the
+        # reference's masks / edts / boundaries .repeat(G, ...) copies, main.py:472-479, are not made)
+        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, batch["masks"], batch["edts_barrier"])
         pred_proj = self.renderer.project_points(pred_v, cam)
-        bdt = loss_utils.bds_loss(pred_proj, batch["boundaries"].repeat(G, 1, 1), faces, pix_to_face,
-                                  reduce=False)
+        bdt = loss_utils.bds_loss(pred_proj, batch["boundaries"], faces, pix_to_face, reduce=False)
         sil_cons = o.edt_reg_wt * edt + o.bdt_reg_wt * bdt
         return mask_pred, l1, sil_cons
 
@@ -190,10 +190,12 @@ class MultiframeStep(nn.Module):
             # the LPIPS part of the reference's texture loss is out of scope)
             tex = textures    # [N,...] shared by the G hypotheses of a frame: the op indexes n % N (= repeat(G))
             tex_pred, _, _ = self.tex_renderer(pred_v.detach(), faces, cam, textures=tex)
-            imgs_f, cam_f, _, masks_f = harness.mirror_sample(imgs, cam, mask_pred, batch["masks"])
+            # main.py:97-110 (mirror_sample) without flipping the rendered masks nobody reads
+            imgs_f, masks_f = torch.flip(imgs, dims=(3,)), torch.flip(batch["masks"], dims=(2,))
+            cam_f = harness._mirrored_pose(cam)
             tex_pred_f, _, _ = self.tex_renderer(pred_v.detach(), faces, cam_f, textures=tex)
-            mse = 0.5 * (loss_utils.masked_texture_mse(tex_pred, imgs.repeat(G, 1, 1, 1), batch["masks"].repeat(G, 1, 1))
-                         + loss_utils.masked_texture_mse(tex_pred_f, imgs_f.repeat(G, 1, 1, 1), masks_f.repeat(G, 1, 1)))
+            mse = 0.5 * (loss_utils.masked_texture_mse(tex_pred, imgs, batch["masks"])
+                         + loss_utils.masked_texture_mse(tex_pred_f, imgs_f, masks_f))
             total = total + o.tex_loss_wt * mse.reshape(G, N)
             terms["tex_mse"] = mse.mean().detach()
         # hypothesis weighting (main.py:735-746)

@@ -55,7 +55,9 @@ def fused_silhouette_losses(mask_pred, mask_gt, edt, eps=1e-6):
     """One pass over the rendered mask for all three silhouette terms
     -> (l1 [N], iou [N], edt [N]); equals l1_loss / iou / edt_loss with reduce=False."""
     N = mask_pred.shape[0]
-    out = ops.mask_losses(mask_pred.reshape(N, -1), mask_gt.reshape(N, -1), edt.reshape(N, -1))
+    # mask_gt / edt may be [N/G, ...]: the ground truth of a frame shared by its G hypotheses
+    out = ops.mask_losses(mask_pred.reshape(N, -1), mask_gt.reshape(mask_gt.shape[0], -1),
+                          edt.reshape(edt.shape[0], -1))
     return out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]
 
 

@@ -484,6 +484,16 @@ def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gam
 
 
 # ------------------------------------------------------------------------------ mask losses
+def _ref_batch(N, ref, what):
+    """References (ground-truth masks, images, boundary points) may be given once per frame for the G
+    hypotheses rendered of it: [N/G, ...] against N predictions, prediction n <-> reference n % (N/G)
+    (= the trainer's ref.repeat(G, ...) without the copies)."""
+    RB = ref.shape[0]
+    if RB <= 0 or N % RB != 0:
+        raise ValueError("%s: %d references for %d predictions (must divide)" % (what, RB, N))
+    return RB
+
+
 class _MaskLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, gt, edt):
@@ -491,14 +501,21 @@ class _MaskLosses(torch.autograd.Function):
         m = _f32c(mask)
         N = m.shape[0]
         HW = m[0].numel()
-        g = _f32c(gt).reshape(N, HW) if gt is not None else None
-        e = _f32c(edt).reshape(N, HW) if edt is not None else None
+        g = _f32c(gt).reshape(-1, HW) if gt is not None else None
+        e = _f32c(edt).reshape(-1, HW) if edt is not None else None
+        RB = N
+        for r in (g, e):
+            if r is not None:
+                RB = _ref_batch(N, r, "mask_losses")
+        if g is not None and e is not None and g.shape[0] != e.shape[0]:
+            raise ValueError("mask_losses: gt and edt must have the same batch")
         out = torch.empty((N, 4), dtype=torch.float32, device=m.device)
         with torch.cuda.device(m.device):
-            _lib.check(_lib.lib().acfm_mask_losses(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e), N, HW,
+            _lib.check(_lib.lib().acfm_mask_losses(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e), N, HW, RB,
                                                    _lib.ptr(out), _lib.cur_stream(m.device)),
                        "acfm_mask_losses")
         ctx.save_for_backward(m, g, e)
+        ctx.rb = RB
         return out
 
     @staticmethod
@@ -510,14 +527,15 @@ class _MaskLosses(torch.autograd.Function):
         gm = torch.empty_like(m)
         with torch.cuda.device(m.device):
             _lib.check(_lib.lib().acfm_mask_losses_backward(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e),
-                                                            _lib.ptr(go), N, HW, _lib.ptr(gm),
+                                                            _lib.ptr(go), N, HW, ctx.rb, _lib.ptr(gm),
                                                             _lib.cur_stream(m.device)),
                        "acfm_mask_losses_backward")
         return gm, None, None
 
 
 def mask_losses(mask, gt=None, edt=None):
-    """One pass over the mask -> [N,4] = (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m)."""
+    """One pass over the mask -> [N,4] = (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m).
+    gt / edt: [N,...] or [N/G,...] shared by G hypotheses per frame (see _ref_batch)."""
     return _MaskLosses.apply(mask, gt, edt)
 
 
@@ -528,13 +546,15 @@ class _TexMSE(torch.autograd.Function):
         t, i, m = _f32c(tex), _f32c(img), _f32c(mask)
         N = t.shape[0]
         HW = m[0].numel()
-        if t.shape != i.shape or t.shape[1] != 3 or t[0, 0].numel() != HW:
-            raise ValueError("tex/img must be [N,3,H,W] and mask [N,H,W]")
+        RB = _ref_batch(N, i, "tex_mse")
+        if t.shape[1:] != i.shape[1:] or t.shape[1] != 3 or t[0, 0].numel() != HW or m.shape[0] != RB:
+            raise ValueError("tex [N,3,H,W], img [N or N/G,3,H,W] and mask [same batch as img,H,W]")
         out = torch.empty((N,), dtype=torch.float32, device=t.device)
         with torch.cuda.device(t.device):
-            _lib.check(_lib.lib().acfm_tex_mse(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), N, HW, _lib.ptr(out),
+            _lib.check(_lib.lib().acfm_tex_mse(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), N, HW, RB, _lib.ptr(out),
                                                _lib.cur_stream(t.device)), "acfm_tex_mse")
         ctx.save_for_backward(t, i, m)
+        ctx.rb = RB
         return out
 
     @staticmethod
@@ -546,7 +566,7 @@ class _TexMSE(torch.autograd.Function):
         gt = torch.empty_like(t)
         with torch.cuda.device(t.device):
             _lib.check(_lib.lib().acfm_tex_mse_backward(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), _lib.ptr(g),
-                                                        N, HW, _lib.ptr(gt), _lib.cur_stream(t.device)),
+                                                        N, HW, ctx.rb, _lib.ptr(gt), _lib.cur_stream(t.device)),
                        "acfm_tex_mse_backward")
         return gt, None, None
 
@@ -584,13 +604,15 @@ class _BdsLoss(torch.autograd.Function):
         v, b = _f32c(verts_xy), _f32c(bds)
         N, V, _ = v.shape
         P = b.shape[1]
+        RB = _ref_batch(N, b, "bds_loss")
         loss = torch.empty((N,), dtype=torch.float32, device=v.device)
         arg = torch.empty((N, P), dtype=torch.int32, device=v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_bds_loss(_lib.ptr(v), _lib.ptr(b), _lib.ptr(vis.contiguous()), N,
-                                                V, P, _lib.ptr(loss), _lib.ptr(arg),
+                                                V, P, RB, _lib.ptr(loss), _lib.ptr(arg),
                                                 _lib.cur_stream(v.device)), "acfm_bds_loss")
         ctx.save_for_backward(v, b, arg)
+        ctx.rb = RB
         return loss
 
     @staticmethod
@@ -602,7 +624,7 @@ class _BdsLoss(torch.autograd.Function):
         gv = torch.empty_like(v)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_bds_loss_backward(_lib.ptr(v), _lib.ptr(b), _lib.ptr(arg),
-                                                         _lib.ptr(g), N, V, P, _lib.ptr(gv),
+                                                         _lib.ptr(g), N, V, P, ctx.rb, _lib.ptr(gv),
                                                          _lib.cur_stream(v.device)),
                        "acfm_bds_loss_backward")
         return gv, None, None

@@ -237,23 +237,27 @@ int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, i
 /* ---- fused silhouette losses ---------------------------------------------------------
  * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False
  * (multiframe/nnutils/loss_utils.py:18-32, 72-77, 245-253) in one pass over the mask:
- *   out [N,4] = (mean|m-gt|, sum m*gt, sum (m+gt-m*gt), mean edt*m); gt / edt may be NULL. */
-int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW,
+ *   out [N,4] = (mean|m-gt|, sum m*gt, sum (m+gt-m*gt), mean edt*m); gt / edt may be NULL.
+ * ref_batch (here and in the losses below): the number of distinct references; prediction n is
+ * compared with reference n % ref_batch (gt, edt [ref_batch,HW]).  The trainer scores G camera
+ * hypotheses per frame against the frame's one ground truth (masks.repeat(G, 1, 1) at
+ * main.py:472-479, 644-662): ref_batch = N / G spares those copies; ref_batch = N is the plain case. */
+int acfm_mask_losses(const float* mask, const float* gt, const float* edt, int N, int HW, int ref_batch,
                      float* out, void* stream);
 /* grad_mask [N,HW] = w_l1[n]*sign(m-gt)/HW + w_edt[n]*edt/HW + IoU term
  * (w_inter[n]*gt + w_union[n]*(1-gt)); weights are per-mesh upstream gradients [N,4]. */
 int acfm_mask_losses_backward(const float* mask, const float* gt, const float* edt,
-                              const float* grad_out, int N, int HW, float* grad_mask,
+                              const float* grad_out, int N, int HW, int ref_batch, float* grad_mask,
                               void* stream);
 
 /* ---- masked texture MSE ---------------------------------------------------------------
  * replaces the inline texture term of multiframe/main.py:655-662,
  * F.mse_loss(texture_pred * mask, imgs * mask, reduction='none').mean((1,2,3)):
- *   tex, img [N,3,HW] f32, mask [N,HW] f32 -> out [N]; backward -> grad_tex [N,3,HW]. */
-int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, float* out,
-                 void* stream);
+ *   tex [N,3,HW], img [ref_batch,3,HW], mask [ref_batch,HW] f32 -> out [N]; backward -> grad_tex [N,3,HW]. */
+int acfm_tex_mse(const float* tex, const float* img, const float* mask, int N, int HW, int ref_batch,
+                 float* out, void* stream);
 int acfm_tex_mse_backward(const float* tex, const float* img, const float* mask,
-                          const float* grad_out, int N, int HW, float* grad_tex, void* stream);
+                          const float* grad_out, int N, int HW, int ref_batch, float* grad_tex, void* stream);
 
 /* ---- visibility + boundary loss ------------------------------------------------------
  * visible-vertex bitmap shared by loss_utils.bds_loss (:214-224) and optical_flow_loss
@@ -263,11 +267,11 @@ int acfm_visible_vertices(const int64_t* pix_to_face, const int64_t* faces, int 
                           int HW, int K, uint8_t* vis, void* stream);
 /* loss_utils.bds_loss (:204-237) given vis: for each boundary point the squared distance to
  * the nearest visible projected vertex (1000 where none), times the point's valid flag,
- * summed per mesh.  verts_xy [N,V,2], bds [N,P,3] -> loss [N], argmin [N,P] i32 (saved). */
+ * summed per mesh.  verts_xy [N,V,2], bds [ref_batch,P,3] -> loss [N], argmin [N,P] i32 (saved). */
 int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, int N, int V, int P,
-                  float* loss, int32_t* argmin, void* stream);
+                  int ref_batch, float* loss, int32_t* argmin, void* stream);
 int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_t* argmin,
-                           const float* grad_loss, int N, int V, int P, float* grad_verts_xy,
+                           const float* grad_loss, int N, int V, int P, int ref_batch, float* grad_verts_xy,
                            void* stream);
 
 /* ---- mesh priors -------------------------------------------------------------------------

@@ -504,3 +504,46 @@ def test_correlation_cost_volume_vs_oracle():
         np.testing.assert_allclose(out[:, ((2 * md + 1) ** 2) // 2].cpu().numpy(), (f1 * f2).mean(1), rtol=1e-4, atol=1e-5)
     with pytest.raises(NotImplementedError):
         Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)
+
+
+def test_losses_with_references_shared_by_hypotheses(meshes):
+    """gt / edt / images / boundary points given once per frame for G hypotheses ([N/G,...] against N
+    predictions, ref_batch in the C ABI) == the trainer's ref.repeat(G, ...), values and gradients."""
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    d = _d()
+    torch.manual_seed(9)
+    G, n0, H = 3, 4, 32
+    N = G * n0
+    mask = torch.rand(N, H, H, device=d)
+    gt, edt = (torch.rand(n0, H, H, device=d) > 0.5).float(), torch.rand(n0, 1, H, H, device=d)
+    w = torch.randn(N, 3, device=d)
+    a = mask.clone().requires_grad_(True)
+    la = torch.stack(L.fused_silhouette_losses(a, gt, edt), 1)
+    (la * w).sum().backward()
+    b = mask.clone().requires_grad_(True)
+    lb = torch.stack(L.fused_silhouette_losses(b, gt.repeat(G, 1, 1), edt.repeat(G, 1, 1, 1)), 1)
+    (lb * w).sum().backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
+    tex, img = torch.rand(N, 3, H, H, device=d), torch.rand(n0, 3, H, H, device=d)
+    ta = tex.clone().requires_grad_(True)
+    ma = L.masked_texture_mse(ta, img, gt)
+    (ma * w[:, 0]).sum().backward()
+    tb = tex.clone().requires_grad_(True)
+    mb = L.masked_texture_mse(tb, img.repeat(G, 1, 1, 1), gt.repeat(G, 1, 1))
+    (mb * w[:, 0]).sum().backward()
+    assert torch.equal(ma, mb) and torch.equal(ta.grad, tb.grad)
+    V, P = 50, 70
+    xy = torch.rand(N, V, 2, device=d) * 2 - 1
+    bds = torch.cat([torch.rand(n0, P, 2, device=d) * 2 - 1, (torch.rand(n0, P, 1, device=d) > 0.2).float()], -1)
+    vis = (torch.rand(N, V, device=d) > 0.3).to(torch.uint8)
+    xa = xy.clone().requires_grad_(True)
+    ba = ops.bds_loss_per_mesh(xa, bds, vis)
+    (ba * w[:, 1]).sum().backward()
+    xb = xy.clone().requires_grad_(True)
+    bb = ops.bds_loss_per_mesh(xb, bds.repeat(G, 1, 1), vis)
+    (bb * w[:, 1]).sum().backward()
+    assert torch.equal(ba, bb)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)   # float atomics
+    with pytest.raises(ValueError):
+        L.fused_silhouette_losses(mask[:10], gt, edt)                 # 10 predictions, 4 references
