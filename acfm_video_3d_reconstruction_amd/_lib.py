@@ -46,6 +46,7 @@ SIGNATURES = {
     "acfm_vertex_color_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
                                        _i, _f, _vp]),
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_backward_faces": (_i, [_vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

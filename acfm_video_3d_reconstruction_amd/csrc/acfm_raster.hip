@@ -28,6 +28,9 @@
 namespace acfm {
 
 int g_split_mode = -3;   // < 0: automatic, split while longest block > (-mode / 2) x mean work per wave slot; 0 never; 1 always
+// A raster launch has entries / div workgroups per XCD group (see Sched): the flagged-empty blocks
+// -- 70 % of a 256^2 frame of the bird -- cost no workgroup dispatch of their own.
+int g_grid_div[3] = {4, 2, 4};   // measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us
 
 constexpr int RBLK = 8;       // pixels per block side: one wave64 per block
 constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
   if (threadIdx.x == 0) {
     int acc = 0;
     for (int c = 0; c < NCLASS; ++c) { s_base[c] = acc; acc += s_hist[c]; }
+    ws.n_work[g] = s_base[NCLASS - 1];   // the flagged-empty class sits at the end of the order
     // Split the heaviest blocks over four workgroups each?  It adds ~25 % work to those blocks and
     // shortens the longest one about 3x: worth it while the group's longest block (in candidate
     // faces ~ walk iterations) outweighs its total work spread over the XCD's 384 wave slots.
@@ -296,32 +300,64 @@ struct Tile {
   float t_xmin, t_xmax, t_ymin, t_ymax;
 };
 
-// Workgroup (= one wave) -> (mesh, 8x8 block) through the heavy-first order of its XCD group.
+// Workgroup (= one wave) -> entries of the heavy-first order of its XCD group.
 // Workgroups are dealt round-robin over the 8 XCDs, so with N % 8 == 0 group g = b % 8 owns the
 // meshes n % 8 == g (one XCD's L2 then holds the records of the meshes it renders).  Pure speed:
 // any mapping gives the same result.
-__device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H, bool with_split) {
+// A group of `per` entries gets stride = ceil(per / div) workgroups (+ 4 per split slot in front).
+// Workgroup j renders the entries j, j + stride, ... that have work (e < n_work: normally just
+// one, the order is heavy-first and most of a frame is empty) and, in the forward kernels, first
+// stores the constant outputs of the flagged-empty entries n_work + j, n_work + j + stride, ...:
+// those stores drain while the block is rendered, and an empty block costs no workgroup dispatch
+// (65 536 one-wave workgroups per 64 frames took ~90 us of the chip's dispatcher by themselves).
+struct Sched {
+  int G, g, per, j0, stride, e_end, n_work, sub;
+};
+__device__ __forceinline__ Sched make_sched(const RasterWs& ws, int N, int H, bool with_split) {
+  Sched s;
+  const int tiles = (H + RBLK - 1) / RBLK;
+  const int tt = tiles * tiles;
+  s.G = (N & 7) == 0 ? 8 : 1;
+  s.per = (N / s.G) * tt;
+  const int nsplit = with_split ? s.G * ws.split_slots * 4 : 0;
+  int b = (int)blockIdx.x;
+  s.sub = -1;
+  if (b < nsplit) {          // split role: workgroups 4 slot .. 4 slot + 3 of a group take the four 4x4 groups of entry `slot`
+    s.g = s.G == 8 ? (b & 7) : 0;
+    const int q = s.G == 8 ? (b >> 3) : b;
+    s.j0 = q >> 2;
+    s.sub = q & 3;
+    s.stride = 1;
+    s.n_work = ws.n_work[s.g];
+    s.e_end = min(s.j0 + 1, s.n_work);
+  } else {
+    b -= nsplit;
+    s.g = s.G == 8 ? (b & 7) : 0;
+    s.j0 = s.G == 8 ? (b >> 3) : b;
+    s.stride = ((int)gridDim.x - nsplit) / s.G;
+    s.n_work = ws.n_work[s.g];
+    s.e_end = s.n_work;
+  }
+  return s;
+}
+
+// order entry -> (mesh, first pixel row, first pixel column) of its 8x8 block
+__device__ __forceinline__ void entry_block(int eo, const Sched& s, int H, int& n, int& by, int& bx) {
+  const int tiles = (H + RBLK - 1) / RBLK;
+  const int tt = tiles * tiles;
+  const int e = eo & ~ENTRY_FLAGS;
+  n = (e / tt) * s.G + s.g;
+  const int tl = e % tt;
+  by = (tl / tiles) * RBLK; bx = (tl % tiles) * RBLK;
+}
+
+__device__ __forceinline__ Tile make_tile(const RasterWs& ws, const Sched& s, int j, int N, int H, bool with_split) {
   Tile t;
   const int tiles = (H + RBLK - 1) / RBLK;
   const int tt = tiles * tiles;
-  const int G = (N & 7) == 0 ? 8 : 1;
-  const int per = (N / G) * tt;
-  const int nsplit = with_split ? G * ws.split_slots * 4 : 0;
-  int b = (int)blockIdx.x;
+  const int G = s.G, g = s.g, per = s.per;
   t.none = false;
-  t.sub = -1;
-  int g, j;
-  if (b < nsplit) {          // split role: workgroups 4 slot .. 4 slot + 3 of a group take the four 4x4 groups of entry `slot`
-    g = G == 8 ? (b & 7) : 0;
-    const int q = G == 8 ? (b >> 3) : b;
-    j = q >> 2;
-    t.sub = q & 3;
-    if (j >= per) { t.none = true; j = 0; }
-  } else {
-    b -= nsplit;
-    g = G == 8 ? (b & 7) : 0;
-    j = G == 8 ? (b >> 3) : b;
-  }
+  t.sub = s.sub;
   const int eo = ws.order[(size_t)g * per + j];
   if (t.sub >= 0 && !(eo & ENTRY_SPLIT)) t.none = true;
   if (t.sub < 0 && with_split && (eo & ENTRY_SPLIT)) t.none = true;   // rendered by its four split workgroups
@@ -329,7 +365,11 @@ __device__ __forceinline__ Tile make_tile(const RasterWs& ws, int N, int H, bool
   t.empty = (eo & ENTRY_EMPTY) != 0;
   const int n = (e / tt) * G + g, tl = e % tt;
   t.n = n;
-  t.tid = threadIdx.x; t.wv = 0; t.lane = t.tid & 63;
+  // (opaque to the optimiser: lane-derived addressing stays inside the per-block code instead of
+  // being hoisted out of the workgroup's block loop into long-lived registers)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  t.tid = tid_; t.wv = 0; t.lane = t.tid & 63;
   const int ty = tl / tiles, tx = tl % tiles;
   // the 8x8 pixels = four 4x4 blocks, one per 16-lane group (= one DPP row); split role: all four
   // 16-lane groups hold the same 4x4 pixels
@@ -731,28 +771,51 @@ struct FwdLds {
   unsigned short wl[RCAP];
 };
 
+// Constant outputs of a flagged-empty 8x8 block (no face box comes near it): exactly what
+// fwd_block leaves for a block without candidates.  Lane i owns pixel (i / 8, i % 8) of the block;
+// the K ids of the soft kernel go out as 16-byte pieces in image order (8 rows of 64 K bytes).
+template <int K, bool TEX>
+__device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by, int bx, int H, int lane) {
+  const int yi = by + (lane >> 3), xi = bx + (lane & 7);
+  const bool valid = (yi < H) && (xi < H);
+  const size_t pix = ((size_t)n * H + yi) * H + xi;
+  if constexpr (K == 1) {
+    if (!valid) return;
+    out.p2f[pix] = (int64_t)-1;
+    if (TEX) {
+      const size_t HW = (size_t)H * H;
+      float* img = out.imgs + (size_t)n * 3 * HW + (size_t)yi * H + xi;
+      img[0] = 0.f; img[HW] = 0.f; img[2 * HW] = 0.f;
+      out.sil[pix] = 0.f;
+      out.tidx[pix] = -1;
+    }
+  } else {
+    if (valid) {
+      out.mask[pix] = 0.0f;
+      if (out.kth) out.kth[pix] = KEY_NONE;
+      if (out.kout == 1) out.p2f[pix] = (long long)-1;
+    }
+    if (out.kout == 1) return;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    constexpr int CH = K / 2;
+    ll2 v; v.x = -1; v.y = -1;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = i * 64 + lane;             // piece index: 8 rows x (8 pixels x CH pieces)
+      const int r = c / (8 * CH), off = c % (8 * CH);
+      if (by + r < H && bx + off / CH < H)
+        reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = v;
+    }
+  }
+}
+
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
-                                                    float sigma, FwdOut out) {
-  __shared__ __attribute__((aligned(16))) FwdLds S;
+__device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
+                                          const FwdOut& out, FwdLds& S) {
   CandList& L = S.L;
   int* s_fl = S.fl;
-  const Tile t = make_tile(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
-  if (t.none) return;
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
-  struct Stamp {
-    unsigned long long* p; unsigned long long t0;
-    __device__ Stamp(unsigned long long* q) : p(q), t0(q ? __builtin_amdgcn_s_memrealtime() : 0) {}
-    __device__ ~Stamp() {
-      if (p && threadIdx.x == 0) {
-        unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
-        p[3 * (size_t)blockIdx.x] = t0; p[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        p[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
-      }
-    }
-  } stamp(out.dbg);
 
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
@@ -924,6 +987,41 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(
   }
 }
 
+template <int K, bool CLIP, bool TEX>
+__global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+                                                    float sigma, FwdOut out) {
+  __shared__ __attribute__((aligned(16))) FwdLds S;
+  const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
+  struct Stamp {
+    unsigned long long* p; unsigned long long t0;
+    __device__ Stamp(unsigned long long* q) : p(q), t0(q ? __builtin_amdgcn_s_memrealtime() : 0) {}
+    __device__ ~Stamp() {
+      if (p && threadIdx.x == 0) {
+        unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+        p[3 * (size_t)blockIdx.x] = t0; p[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+      }
+    }
+  } stamp(out.dbg);
+  const int lane = threadIdx.x & 63;
+  if (sc.sub < 0) {
+    // this workgroup's share of the flagged-empty blocks: fire-and-forget stores, issued first
+#pragma unroll 1
+    for (int e = sc.n_work + sc.j0; e < sc.per; e += sc.stride) {
+      int n, by, bx;
+      entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+      fwd_fill_block<K, TEX>(out, n, by, bx, H, lane);
+    }
+  }
+#pragma unroll 1
+  for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
+    const Tile t = make_tile(ws, sc, e, N, H, K > 1);
+    if (!t.none) fwd_block<K, CLIP, TEX>(ws, t, F, H, blur, sigma, out, S);
+    wave_lds_sync();   // the next block reuses the LDS lists
+  }
+}
+
 // ------------------------------------------------------------------------------- backward
 // Sum over the 16 lanes of a DPP row (= one 4x4 pixel block): four row shifts, the total lands
 // in lane 15 of the row.
@@ -957,20 +1055,10 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
   gbx = g * t * ex; gby = g * t * ey;
 }
 
-__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
-                                                 const unsigned long long* __restrict__ kth,
-                                                 const float* __restrict__ grad_mask, int N, int V,
-                                                 int F, int H, float blur, float sigma) {
-  __shared__ CandList L;
-  __shared__ int s_fl[FLCAP];
-  // gradient accumulator per list slot: (d/dx0, d/dy0, d/dx1, d/dy1, d/dx2, d/dy2) of that face,
-  // summed over the block's pixels; flushed (global float atomics on the face's three vertices)
-  // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
-  // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
-  __shared__ float s_acc[RCAP][6];
-  const Tile t = make_tile(ws, N, H, true);
-  if (t.none) return;
-
+__device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const float* __restrict__ mask,
+                                              const unsigned long long* __restrict__ kth,
+                                              const float* __restrict__ grad_mask, int V, int F, int H, float blur,
+                                              float sigma, CandList& L, int* s_fl, float (*s_acc)[6]) {
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
@@ -1055,6 +1143,26 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
       }
     }
   });
+}
+
+__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
+                                                 const unsigned long long* __restrict__ kth,
+                                                 const float* __restrict__ grad_mask, int N, int V,
+                                                 int F, int H, float blur, float sigma) {
+  __shared__ CandList L;
+  __shared__ int s_fl[FLCAP];
+  // gradient accumulator per list slot: (d/dx0, d/dy0, d/dx1, d/dy1, d/dx2, d/dy2) of that face,
+  // summed over the block's pixels; flushed (global float atomics on the face's three vertices)
+  // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
+  // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
+  __shared__ float s_acc[RCAP][6];
+  const Sched sc = make_sched(ws, N, H, true);
+#pragma unroll 1
+  for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
+    const Tile t = make_tile(ws, sc, e, N, H, true);
+    if (!t.none) sil_bwd_block(ws, t, mask, kth, grad_mask, V, F, H, blur, sigma, L, s_fl, s_acc);
+    wave_lds_sync();
+  }
 }
 
 // ------------------------------------------------------------------------------- projection
@@ -1149,6 +1257,58 @@ __global__ void k_tex_bwd(const float* __restrict__ grad_imgs, const int32_t* __
   atomicAdd(&grad_atlas[(size_t)t * 3 + 1], g[HW]);
   atomicAdd(&grad_atlas[(size_t)t * 3 + 2], g[2 * HW]);
 }
+// Gather form of the same gradient, one wave per (atlas, face): the wave visits the pixels of the
+// face's box in every mesh that samples this atlas (the G hypotheses of a frame), adds the
+// gradients of the pixels whose texel belongs to the face into 3 R^2 LDS accumulators and stores
+// the face's texels -- zeros included -- with plain coalesced stores.  No global atomics (agent-
+// scope float atomics execute at the memory side on this multi-XCD part: 2 M of them took 87 us)
+// and no zero fill of the 35 MB gradient.  Needs the face boxes of the forward's workspace.
+constexpr int TEXG_MAX_R = 8;
+__global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float* __restrict__ grad_imgs,
+                                                       const int32_t* __restrict__ tidx, int N, int F, int H,
+                                                       int R, int NA, float box_shrink,
+                                                       float* __restrict__ grad_atlas) {
+  __shared__ float s_acc[4][3 * TEXG_MAX_R * TEXG_MAX_R];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long af = (long long)blockIdx.x * 4 + wv;      // atlas * F + face
+  if (af >= (long long)NA * F) return;                       // (whole wave; no workgroup barriers below)
+  const int a = (int)(af / F), f = (int)(af % F);
+  const int R2 = R * R, n3 = 3 * R2;
+  float* acc = s_acc[wv];
+  for (int i = lane; i < n3; i += 64) acc[i] = 0.f;
+  wave_lds_sync();
+  const int base = (int)af * R2;                             // first texel index of this face (< 2^31: host check)
+  const size_t HW = (size_t)H * H;
+  const float hf = (float)H;
+  for (int n = a; n < N; n += NA) {
+    float4 b = ws.box[(size_t)n * F + f];
+    b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
+    if (!(b.x <= b.y && b.z <= b.w)) continue;               // degenerate face (inf, -inf, ..) or emptied box
+    // pixel range of the box, one pixel of slack: the formula of k_setup's coarse masks
+    int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+    int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+    int ya = (int)floorf(hf - 1.0f - ((b.w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+    int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+    if (xb < 0 || yb < 0 || xa >= H || ya >= H) continue;
+    xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
+    const int w = xb - xa + 1, cnt = w * (yb - ya + 1);
+    const int32_t* tn = tidx + (size_t)n * HW;
+    const float* gn = grad_imgs + (size_t)n * 3 * HW;
+    for (int i = lane; i < cnt; i += 64) {
+      const size_t p = (size_t)(ya + i / w) * H + (xa + i % w);
+      const int t = tn[p] - base;
+      if (t >= 0 && t < R2) {
+        // d rgb / d texel = wnum / (wnum + delta) = 1 in fp32 (wnum >= 0.5, delta = 1e-10)
+        atomicAdd(&acc[3 * t + 0], gn[p]);
+        atomicAdd(&acc[3 * t + 1], gn[HW + p]);
+        atomicAdd(&acc[3 * t + 2], gn[2 * HW + p]);
+      }
+    }
+  }
+  wave_lds_sync();
+  float* o = grad_atlas + (size_t)base * 3;
+  for (int i = lane; i < n3; i += 64) o[i] = acc[i];
+}
 
 // ------------------------------------------------------------------------------- profiling
 static bool g_prof_on = false;
@@ -1200,17 +1360,20 @@ static bool bad_dims(int N, int V, int F, int H) {
          (size_t)N * ((H + RBLK - 1) / RBLK) * ((H + RBLK - 1) / RBLK) > 0x7fffffffull;
 }
 
-static unsigned tile_grid(int N, int H, int split_slots = 0) {
+// workgroups of a raster launch: per XCD group ceil(entries / div) (+ 4 per split slot), see Sched
+static unsigned tile_grid(int N, int H, int div, int split_slots = 0) {
   const int tiles = (H + RBLK - 1) / RBLK;
   const size_t G = (N & 7) == 0 ? 8 : 1;
-  return (unsigned)((size_t)tiles * tiles * N + G * (size_t)split_slots * 4);
+  const size_t per = (size_t)tiles * tiles * (N / G);
+  const size_t d = div < 1 ? 1 : (size_t)div;
+  return (unsigned)(G * ((per + d - 1) / d + (size_t)split_slots * 4));
 }
 
 template <int K>
 static int launch_sil_fwd(const RasterWs& ws, int N, int F, int H, float blur, float sigma,
                           const FwdOut& out, hipStream_t st) {
   ProfScope ps(ACFM_PROF_SIL_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H, ws.split_slots)), dim3(RT), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H, g_grid_div[0], ws.split_slots)), dim3(RT), 0, st, ws, N, F,
                      H, blur, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1255,6 +1418,8 @@ int acfm_prof_collect(float* ms_host, int* count_host, int n) {
 
 // diagnostic (not in the public header): override the block-splitting heuristic (-1 auto, 0 off, 1 on)
 void acfm_debug_set_split(int mode) { acfm::g_split_mode = mode; }
+// diagnostic: workgroups per group = entries / div (which: 0 K-nearest forward, 1 nearest-face forward, 2 backward)
+void acfm_debug_set_grid_div(int which, int div) { if (which >= 0 && which < 3 && div >= 1) acfm::g_grid_div[which] = div; }
 
 // diagnostic (not in the public header): resident workgroups per CU of the raster kernels
 int acfm_debug_occupancy(int which, int dyn_lds) {
@@ -1352,7 +1517,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, ws.split_slots)), dim3(RT), lds, st, ws, mask,
+    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, g_grid_div[2], ws.split_slots)), dim3(RT), lds, st, ws, mask,
                        reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
                        blur_radius, sigma);
   }
@@ -1381,7 +1546,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   out.vis = vis;
   out.V = V;
   ProfScope ps(ACFM_PROF_HARD_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F,
                      H, 0.f, 1e-4f, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1411,7 +1576,7 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.atlas_n = atlas_batch;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1439,7 +1604,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
   out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
   out.atlas = verts_rgb;  // never dereferenced when vrgb is set
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H)), dim3(RT), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1457,6 +1622,24 @@ int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, i
   ProfScope ps(ACFM_PROF_TEX_BWD, st);
   hipLaunchKernelGGL(k_tex_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grad_imgs,
                      texel_idx, (size_t)H * H, total, grad_atlas);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
+                            float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
+                            void* stream) {
+  if (!grad_imgs || !texel_idx || !grad_atlas || !wsp) return ACFM_E_BADARG;
+  if (bad_dims(N, V, F, H) || R <= 0 || R > TEXG_MAX_R || atlas_batch <= 0 || N % atlas_batch != 0 || !(ws_blur >= 0.f))
+    return ACFM_E_BADARG;
+  if ((size_t)atlas_batch * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(const_cast<void*>(wsp), N, V, F, H);
+  if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t waves = (size_t)atlas_batch * F;
+  ProfScope ps(ACFM_PROF_TEX_BWD, st);
+  hipLaunchKernelGGL(k_tex_bwd_faces, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ws, grad_imgs, texel_idx,
+                     N, F, H, R, atlas_batch, ws_blur > 0.f ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f, grad_atlas);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

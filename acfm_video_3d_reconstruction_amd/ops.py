@@ -404,6 +404,11 @@ def hard_raster(verts_proj, faces, img_size):
 
 
 # ------------------------------------------------------------------------------ texture
+# atlas gradient: gather per face over the pixels of its box (acfm_tex_backward_faces, R <= 8) instead
+# of one global float atomic per pixel and channel (acfm_tex_backward); both are kept and tested
+TEX_BWD_GATHER = True
+
+
 class _TexRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, faces, cams, atlas, img_size, sigma, gamma, offset_z):
@@ -430,7 +435,8 @@ class _TexRender(torch.autograd.Function):
                 _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
                 _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
-        ctx.cfg = (N, F, H, R, NA)
+        ctx.cfg = (N, F, H, R, NA, V)
+        ctx.ws = (ws, nb, float(ws_blur))   # face boxes: the gather form of the atlas gradient walks them
         ctx.mark_non_differentiable(sil, p2f)
         ctx.set_materialize_grads(False)
         return imgs, sil, p2f
@@ -438,15 +444,21 @@ class _TexRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gimgs, _gs, _gp):
         (tidx,) = ctx.saved_tensors
-        N, F, H, R, NA = ctx.cfg
+        N, F, H, R, NA, V = ctx.cfg
         ga = None
         if ctx.needs_input_grad[3] and gimgs is not None:
             g = _f32c(gimgs)
             ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=g.device)
+            ws, nb, ws_blur = ctx.ws
             with torch.cuda.device(g.device):
-                _lib.check(_lib.lib().acfm_tex_backward(_lib.ptr(g), _lib.ptr(tidx), N, F, H, R, NA,
-                                                        _lib.ptr(ga), _lib.cur_stream(g.device)),
-                           "acfm_tex_backward")
+                if TEX_BWD_GATHER and R <= 8:
+                    _lib.check(_lib.lib().acfm_tex_backward_faces(
+                        _lib.ptr(g), _lib.ptr(tidx), _lib.ptr(ws), nb, ws_blur, N, V, F, H, R, NA,
+                        _lib.ptr(ga), _lib.cur_stream(g.device)), "acfm_tex_backward_faces")
+                else:
+                    _lib.check(_lib.lib().acfm_tex_backward(_lib.ptr(g), _lib.ptr(tidx), N, F, H, R, NA,
+                                                            _lib.ptr(ga), _lib.cur_stream(g.device)),
+                               "acfm_tex_backward")
         # geometry / camera: integer texel lookup and K=1 blending send (numerically) no
         # gradient -- |d rgb / d dist| <= 1e-6 |texel| from the delta=1e-10 term.
         return None, None, None, ga, None, None, None, None

@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-oracle time budget")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-lean", action="store_true", help="skip the nearest-plane-only comparison run")
+    p.add_argument("--eager", action="store_true",
+                   help="launch every kernel of the step from Python instead of replaying one captured hipGraph")
     p.add_argument("--tex-stream", type=int, default=0,
                    help="texture branch on its own HIP stream (measured slower: 1.34 vs 1.26 ms/step)")
     return p.parse_args()
@@ -67,6 +69,10 @@ def main():
     if os.environ.get("ACFM_SPLIT") is not None:   # diagnostic: block-splitting heuristic off / on
         from acfm_video_3d_reconstruction_amd import _lib as _l
         ctypes.CDLL(_l.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
+    if os.environ.get("ACFM_DIV") is not None:     # diagnostic: raster workgroups per group = entries / div ("fwdK,fwd1,bwd")
+        from acfm_video_3d_reconstruction_amd import _lib as _l
+        for which, d in enumerate(os.environ["ACFM_DIV"].split(",")):
+            ctypes.CDLL(_l.SO_PATH).acfm_debug_set_grid_div(which, int(d))
     a = parse()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -128,7 +134,7 @@ def main():
 
     side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
 
-    def step(ren=renderer):
+    def compute(ren):
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
         tex_term = None
         if side is not None:
@@ -153,10 +159,40 @@ def main():
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
         g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+        return total.detach(), g_delta, g_cams, g_mean, g_atlas
+
+    def exchange(total, g_mean):
         mean_p.grad = g_mean
         if world > 1:  # the one exchange: shared mean-shape gradient + loss scalar
-            reducer.reduce(extra_scalars=total.detach().reshape(1))
+            reducer.reduce(extra_scalars=total.reshape(1))
+
+    def step(ren=renderer):
+        total, g_delta, g_cams, g_mean, g_atlas = compute(ren)
+        exchange(total, g_mean)
         return total, g_delta, g_cams, g_atlas
+
+    def graphed(ren):
+        """The same step with its ~60 launches (forward, backward, every gradient buffer) captured
+        once into a hipGraph and replayed: shapes are static, every entry point of libacfm_hip.so is
+        stream-ordered, so the step runs at the GPU's pace whatever the host's launch rate is (with
+        8 ranks on one host the Python launch loop is the first thing to fall behind).  The all-reduce
+        of the shared gradient stays an ordinary RCCL call on the replayed buffers."""
+        cur = torch.cuda.current_stream(dev)
+        s2 = torch.cuda.Stream(device=dev)
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s2):
+            for _ in range(3):
+                compute(ren)
+        cur.wait_stream(s2)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = compute(ren)
+
+        def replay(_ren=None):
+            g.replay()
+            exchange(outs[0], outs[3])
+            return outs[0], outs[1], outs[2], outs[4]
+        return replay
 
     def fence():
         torch.cuda.synchronize()
@@ -164,13 +200,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(ren, warmup, steps):
+    def timed(ren, warmup, steps, use_graph=None):
+        use_graph = (not a.eager and side is None) if use_graph is None else use_graph
+        fn = graphed(ren) if use_graph else step
         for _ in range(warmup):
-            step(ren)
+            fn(ren)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(ren)
+            fn(ren)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -182,6 +220,9 @@ def main():
     dt = timed(renderer, a.warmup, a.steps)          # the drop-in API: pix_to_face [N,H,W,20] int64
     ms_step = 1e3 * dt / a.steps
     value = world * N * a.steps / dt
+    use_graph = not a.eager and side is None
+    # the other launch mode of the same step, reported beside the headline (never instead of it)
+    dt_other = timed(renderer, max(2, a.warmup // 2), a.steps, use_graph=not use_graph) if side is None else None
     # same step with only the nearest-face plane of pix_to_face written (all that any caller of
     # the reference reads); reported beside the headline value, never instead of it
     dt_lean = None
@@ -273,6 +314,11 @@ def main():
                        "sharding": "frames over ranks; all-reduce of shared mean-shape grad"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
+        out["launch"] = "one hipGraph replay per step (+ the RCCL all-reduce)" if use_graph else "eager (one Python launch per kernel)"
+        if dt_other:
+            out["hipgraph_replay" if not use_graph else "eager_launch"] = {
+                "value": round(world * N * a.steps / dt_other, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * dt_other / a.steps, 4)}
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",

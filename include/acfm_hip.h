@@ -233,6 +233,13 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
  * Integer texel indexing sends no gradient to geometry. */
 int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R, int atlas_batch,
                       float* grad_atlas, void* stream);
+/* Same gradient in gather form (R <= 8): one wave per (atlas, face) sums the pixels of the face's box
+ * whose texel belongs to it and stores all its texels -- no global atomics, no zero fill.  ws = the
+ * workspace acfm_tex_forward ran on (its face boxes), ws_blur = the blur it was set up with (0 unless
+ * taken over from a silhouette render, ws_ready).  Replaces the TexturesAtlas index_put backward. */
+int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, const void* ws, size_t ws_bytes,
+                            float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
+                            void* stream);
 
 /* ---- fused silhouette losses ---------------------------------------------------------
  * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False

@@ -225,6 +225,43 @@ def test_texture_atlas_shared_by_hypotheses(meshes):
         ops.tex_render(tv, faces, tc, atlas[:1].repeat(4, 1, 1, 1, 1), H)      # 6 meshes, 4 atlases
 
 
+def test_texture_backward_gather_and_scatter_forms(meshes):
+    """The atlas gradient as a per-face gather over the pixels of the face's box
+    (acfm_tex_backward_faces) and as per-pixel global atomics (acfm_tex_backward): both equal the
+    oracle -- stand-alone workspace, a workspace taken over from a silhouette render (boxes carry its
+    blur margin), an atlas shared by G hypotheses, an image size that is no multiple of 8 or 32."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    try:
+        for name, n, G, H, R, share_ws in (("bird", 4, 1, 128, 6, False), ("horse", 4, 2, 100, 4, True),
+                                           ("cow", 3, 1, 67, 8, True), ("bird", 2, 1, 256, 2, False)):
+            verts, f, cams = _setup(meshes, name, n, 61)
+            rng = np.random.default_rng(62)
+            na = n // G
+            atlas = rng.uniform(0, 1, (na, f.shape[0], R, R, 3)).astype(np.float32)
+            g = rng.standard_normal((n, 3, H, H)).astype(np.float32)
+            _, _, _, tidx_ref = O.tex_render(verts, f, cams, np.tile(atlas, (G, 1, 1, 1, 1)), H)
+            ref = O.tex_render_backward_atlas(tidx_ref, g, (n,) + atlas.shape[1:])
+            ref = ref.reshape((G, na) + atlas.shape[1:]).sum(0)
+            tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+            faces = torch.from_numpy(f)[None].to(d).expand(n, -1, -1)
+            got = {}
+            for gather in (True, False):
+                ops.TEX_BWD_GATHER = gather
+                ops._SETUP.clear()
+                if share_ws:
+                    ops.sil_render(tv, faces, tc, H)
+                    assert ops._shared_setup(tv, tc, ops.expand_faces(faces, n), H, 0.0) is not None
+                ta = torch.tensor(atlas, device=d, requires_grad=True)
+                imgs, _, _ = ops.tex_render(tv, faces, tc, ta, H)
+                (imgs * torch.tensor(g, device=d)).sum().backward()
+                got[gather] = ta.grad.cpu().numpy()
+                np.testing.assert_allclose(got[gather], ref, rtol=1e-5, atol=1e-5)
+            assert (got[True] != 0).sum() == (got[False] != 0).sum()
+    finally:
+        ops.TEX_BWD_GATHER = True
+
+
 def test_silhouette_nearest_plane_only(meshes):
     """pix_to_face_slots=1: same mask, same nearest face, same gradients, 1/20 of the id traffic."""
     from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer

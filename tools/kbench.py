@@ -39,6 +39,9 @@ def main():
     lib = _lib.lib()
     if os.environ.get("ACFM_SPLIT") is not None:
         ctypes.CDLL(_lib.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
+    if os.environ.get("ACFM_DIV") is not None:   # workgroups per group = entries / div: "fwdK,fwd1,bwd"
+        for which, d in enumerate(os.environ["ACFM_DIV"].split(",")):
+            ctypes.CDLL(_lib.SO_PATH).acfm_debug_set_grid_div(which, int(d))
 
     def run():
         if "sil" in a.what:
