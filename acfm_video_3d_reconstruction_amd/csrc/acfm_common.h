@@ -47,6 +47,7 @@ struct RasterWs {
   float* grad_ndc; // [N,V,2]
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
+  uint8_t* fvis;   // [N,F] 1 = the face is the nearest one at some pixel of the last texture render on this workspace
   int* n_work;     // [8] per XCD group: entries of its order that have work (the flagged-empty ones follow them)
   int split_slots; // heaviest blocks per XCD group that may be rendered by four workgroups each (raster kernels)
   unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every 32x32-pixel coarse tile (words = ceil(F/64) u64)
@@ -84,6 +85,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
   w.n_work = (int*)(p + o);     o += align256(sizeof(int) * 8);
+  w.fvis = (uint8_t*)(p + o);   o += align256((size_t)N * F);
   const size_t ct = (size_t)((H + 31) / 32) * ((H + 31) / 32), words = ((size_t)F + 63) / 64;
   w.cmask = (unsigned*)(p + o); o += align256(sizeof(unsigned) * 2 * (size_t)N * ct * words);
   w.bytes = o;

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     ws.recC[o] = make_float4(z2, area, 0.f, 0.f);
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
+    ws.fvis[o] = 0;
     if (!degenerate) {
       // pixel index of an NDC coordinate: i = H-1 - ((c+1)H - 1)/2; one pixel of slack
       const float hf = (float)H;
@@ -878,6 +879,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         img[2 * HW] = (wnum * cb + delta * 0.0f) / den;
         out.sil[t.pix] = 1.0f - (1.0f - prob);
         out.tidx[t.pix] = (int32_t)ti;
+        ws.fvis[(size_t)n * F + f] = 1;   // the atlas gradient (k_tex_bwd_faces) visits only faces that were seen
       }
     }
   } else {
@@ -1257,57 +1259,138 @@ __global__ void k_tex_bwd(const float* __restrict__ grad_imgs, const int32_t* __
   atomicAdd(&grad_atlas[(size_t)t * 3 + 1], g[HW]);
   atomicAdd(&grad_atlas[(size_t)t * 3 + 2], g[2 * HW]);
 }
-// Gather form of the same gradient, one wave per (atlas, face): the wave visits the pixels of the
+// Gather form of the same gradient, one wave per four (atlas, face) slots: for each it visits the pixels of the
 // face's box in every mesh that samples this atlas (the G hypotheses of a frame), adds the
 // gradients of the pixels whose texel belongs to the face into 3 R^2 LDS accumulators and stores
 // the face's texels -- zeros included -- with plain coalesced stores.  No global atomics (agent-
 // scope float atomics execute at the memory side on this multi-XCD part: 2 M of them took 87 us)
 // and no zero fill of the 35 MB gradient.  Needs the face boxes of the forward's workspace.
+// i / w and i % w for 0 <= i < 2^23, 0 < w < 2^12 without the ~35-instruction integer division
+__device__ __forceinline__ void divmod_small(int i, int w, float rw, int& q, int& r) {
+  q = (int)((float)i * rw);
+  r = i - q * w;
+  if (r < 0) { --q; r += w; }
+  if (r >= w) { ++q; r -= w; }
+}
 constexpr int TEXG_MAX_R = 8;
+constexpr int TEXG_FPW = 4;      // faces per wave: their boxes, texel indices and gradients are loaded side by side
+constexpr int TEXG_U = 8;        // big boxes: 64 U pixels per round, all their loads in flight together
 __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float* __restrict__ grad_imgs,
                                                        const int32_t* __restrict__ tidx, int N, int F, int H,
                                                        int R, int NA, float box_shrink,
                                                        float* __restrict__ grad_atlas) {
-  __shared__ float s_acc[4][3 * TEXG_MAX_R * TEXG_MAX_R];
+  __shared__ float s_acc[4][TEXG_FPW][3 * TEXG_MAX_R * TEXG_MAX_R];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long af = (long long)blockIdx.x * 4 + wv;      // atlas * F + face
-  if (af >= (long long)NA * F) return;                       // (whole wave; no workgroup barriers below)
-  const int a = (int)(af / F), f = (int)(af % F);
+  // Wave q of the launch takes the faces q, q + Q, q + 2Q, q + 3Q of one atlas (Q = ceil(F / FPW)):
+  // neighbouring faces of a mesh tend to be large together, and a wave walks its faces' boxes one
+  // after the other, so they are dealt to different waves.
+  const int Q = (F + TEXG_FPW - 1) / TEXG_FPW;
+  const long long wq = (long long)blockIdx.x * 4 + wv;
+  if (wq >= (long long)NA * Q) return;                       // (whole wave; no workgroup barriers below)
+  const int a = (int)(wq / Q), f0 = (int)(wq % Q);
   const int R2 = R * R, n3 = 3 * R2;
-  float* acc = s_acc[wv];
-  for (int i = lane; i < n3; i += 64) acc[i] = 0.f;
+  float (*acc)[3 * TEXG_MAX_R * TEXG_MAX_R] = s_acc[wv];
+#pragma unroll
+  for (int k = 0; k < TEXG_FPW; ++k)
+    for (int i = lane; i < n3; i += 64) acc[k][i] = 0.f;
   wave_lds_sync();
-  const int base = (int)af * R2;                             // first texel index of this face (< 2^31: host check)
   const size_t HW = (size_t)H * H;
   const float hf = (float)H;
-  for (int n = a; n < N; n += NA) {
-    float4 b = ws.box[(size_t)n * F + f];
-    b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
-    if (!(b.x <= b.y && b.z <= b.w)) continue;               // degenerate face (inf, -inf, ..) or emptied box
-    // pixel range of the box, one pixel of slack: the formula of k_setup's coarse masks
-    int xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
-    int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
-    int ya = (int)floorf(hf - 1.0f - ((b.w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
-    int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
-    if (xb < 0 || yb < 0 || xa >= H || ya >= H) continue;
-    xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
-    const int w = xb - xa + 1, cnt = w * (yb - ya + 1);
+  // lane k < FPW looks after face f0 + k Q
+  const int my_f = f0 + (lane < TEXG_FPW ? lane : 0) * Q;
+  const bool my_live = lane < TEXG_FPW && my_f < F;
+  const int G = N / NA;
+  for (int g = 0; g < G; ++g) {
+    // the FPW boxes (mesh a + g NA), one per lane, turned into pixel ranges (k_setup's formula, one pixel of slack)
+    int xa = 0, ya = 0, w = 1, cnt = 0;
+    const int n = a + g * NA;
+    if (my_live && ws.fvis[(size_t)n * F + my_f]) {          // (a face no pixel shows has no gradient: zeros)
+      float4 b = ws.box[(size_t)n * F + my_f];
+      b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
+      if (b.x <= b.y && b.z <= b.w) {                        // not a degenerate face (inf, -inf, ..) or an emptied box
+        // pixel range of the box: k_setup's formula with one pixel of slack, then tightened to the
+        // pixels that pass the forward's own test (pixel centre inside the box, same float expressions)
+        xa = (int)floorf(hf - 1.0f - ((b.y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+        int xb = (int)ceilf(hf - 1.0f - ((b.x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+        ya = (int)floorf(hf - 1.0f - ((b.w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+        int yb = (int)ceilf(hf - 1.0f - ((b.z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+        if (!(xb < 0 || yb < 0 || xa >= H || ya >= H)) {
+          xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
+          for (int it = 0; it < 3 && xa <= xb && pix_to_ndc(H - 1 - xa, H) > b.y; ++it) ++xa;
+          for (int it = 0; it < 3 && xa <= xb && pix_to_ndc(H - 1 - xb, H) < b.x; ++it) --xb;
+          for (int it = 0; it < 3 && ya <= yb && pix_to_ndc(H - 1 - ya, H) > b.w; ++it) ++ya;
+          for (int it = 0; it < 3 && ya <= yb && pix_to_ndc(H - 1 - yb, H) < b.z; ++it) --yb;
+          if (xa <= xb && ya <= yb) { w = xb - xa + 1; cnt = w * (yb - ya + 1); }
+        }
+      }
+    }
     const int32_t* tn = tidx + (size_t)n * HW;
     const float* gn = grad_imgs + (size_t)n * 3 * HW;
-    for (int i = lane; i < cnt; i += 64) {
-      const size_t p = (size_t)(ya + i / w) * H + (xa + i % w);
-      const int t = tn[p] - base;
-      if (t >= 0 && t < R2) {
+    int cmax = 0;
+    int t[TEXG_FPW];
+    size_t pp[TEXG_FPW];
+#pragma unroll
+    for (int k = 0; k < TEXG_FPW; ++k) {                     // all texel-index loads first ...
+      const int kxa = __shfl(xa, k, 64), kya = __shfl(ya, k, 64), kw = __shfl(w, k, 64), kc = __shfl(cnt, k, 64);
+      const int kbase = (a * F + f0 + k * Q) * R2;           // first texel index of the face (< 2^31: host check)
+      cmax = max(cmax, kc);
+      t[k] = -1;
+      pp[k] = 0;
+      if (lane < kc) {
+        int qy, qx;
+        divmod_small(lane, kw, __builtin_amdgcn_rcpf((float)kw), qy, qx);
+        pp[k] = (size_t)(kya + qy) * H + (kxa + qx);
+        t[k] = tn[pp[k]] - kbase;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TEXG_FPW; ++k) {                     // ... then the gradients of the pixels that belong to the face
+      if (t[k] >= 0 && t[k] < R2) {
         // d rgb / d texel = wnum / (wnum + delta) = 1 in fp32 (wnum >= 0.5, delta = 1e-10)
-        atomicAdd(&acc[3 * t + 0], gn[p]);
-        atomicAdd(&acc[3 * t + 1], gn[HW + p]);
-        atomicAdd(&acc[3 * t + 2], gn[2 * HW + p]);
+        const float r = gn[pp[k]], gg = gn[HW + pp[k]], bb = gn[2 * HW + pp[k]];
+        atomicAdd(&acc[k][3 * t[k] + 0], r);
+        atomicAdd(&acc[k][3 * t[k] + 1], gg);
+        atomicAdd(&acc[k][3 * t[k] + 2], bb);
+      }
+    }
+    if (cmax > 64) {   // boxes of more than 64 pixels (a third of the bird's): the rest face by face, 64 U pixels per round
+      for (int k = 0; k < TEXG_FPW; ++k) {
+        const int kxa = __shfl(xa, k, 64), kya = __shfl(ya, k, 64), kw = __shfl(w, k, 64), kc = __shfl(cnt, k, 64);
+        const int kbase = (a * F + f0 + k * Q) * R2;
+        const float rw = __builtin_amdgcn_rcpf((float)kw);
+        for (int i0 = 64 + lane; i0 < kc + lane; i0 += 64 * TEXG_U) {   // (i0 - lane is wave-uniform)
+          int tt[TEXG_U];
+          float cr[TEXG_U], cg[TEXG_U], cb[TEXG_U];
+#pragma unroll
+          for (int u = 0; u < TEXG_U; ++u) {
+            const int i = i0 + 64 * u;
+            tt[u] = -1; cr[u] = 0.f; cg[u] = 0.f; cb[u] = 0.f;
+            if (i < kc) {
+              int qy, qx;
+              divmod_small(i, kw, rw, qy, qx);
+              const size_t p = (size_t)(kya + qy) * H + (kxa + qx);
+              tt[u] = tn[p] - kbase;
+              cr[u] = gn[p]; cg[u] = gn[HW + p]; cb[u] = gn[2 * HW + p];   // unconditionally: one round trip per round
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < TEXG_U; ++u)
+            if (tt[u] >= 0 && tt[u] < R2) {
+              atomicAdd(&acc[k][3 * tt[u] + 0], cr[u]);
+              atomicAdd(&acc[k][3 * tt[u] + 1], cg[u]);
+              atomicAdd(&acc[k][3 * tt[u] + 2], cb[u]);
+            }
+        }
       }
     }
   }
   wave_lds_sync();
-  float* o = grad_atlas + (size_t)base * 3;
-  for (int i = lane; i < n3; i += 64) o[i] = acc[i];
+#pragma unroll
+  for (int k = 0; k < TEXG_FPW; ++k) {
+    if (f0 + k * Q >= F) break;
+    float* o = grad_atlas + (size_t)(a * F + f0 + k * Q) * n3;
+    for (int i = lane; i < n3; i += 64) o[i] = acc[k][i];
+  }
 }
 
 // ------------------------------------------------------------------------------- profiling
@@ -1636,7 +1719,7 @@ int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, co
   const RasterWs ws = carve_ws(const_cast<void*>(wsp), N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const size_t waves = (size_t)atlas_batch * F;
+  const size_t waves = (size_t)atlas_batch * ((F + TEXG_FPW - 1) / TEXG_FPW);
   ProfScope ps(ACFM_PROF_TEX_BWD, st);
   hipLaunchKernelGGL(k_tex_bwd_faces, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ws, grad_imgs, texel_idx,
                      N, F, H, R, atlas_batch, ws_blur > 0.f ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f, grad_atlas);
