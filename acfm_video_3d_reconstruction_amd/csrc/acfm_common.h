@@ -38,8 +38,8 @@ struct ProfScope {
 // Workspace carve-up shared by every raster entry point (acfm_raster_workspace_bytes).
 struct RasterWs {
   float* ndc;      // [N,V,3] NDC x, NDC y, view z
-  float4* recA;    // [N,F] (x0,y0,x1,y1)
-  float4* recB;    // [N,F] (x2,y2,z0,z1)
+  float4* recA;    // [N,F] (x0,y0,x1,x2)
+  float4* recB;    // [N,F] (y1,y2,z0,z1)
   float4* recC;    // [N,F] (z2, area, -, -)
   float4* box;     // [N,F] (xmin,xmax,ymin,ymax), blur margin included; degenerate = (inf,-inf,inf,-inf)
   int4* vidx;      // [N,F] (i0,i1,i2,-)
@@ -129,6 +129,33 @@ __device__ __forceinline__ float point_line_dist(float px, float py, float ax, f
   const float qx = ax + t * bax, qy = ay + t * bay;
   const float dx = qx - px, dy = qy - py;
   return dx * dx + dy * dy;
+}
+
+// Two point_line_dist at once on the packed fp32 pipe (v_pk_mul / v_pk_add / v_pk_fma_f32 do two
+// lanes' worth of one IEEE operation per issue slot): the same operations in the same order per
+// component, so each half is bit-identical to point_line_dist.  Segments (ax, ay)-(bx, by), one per component.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f point_line_dist2(float px, float py, v2f ax, v2f ay, v2f bx, v2f by) {
+  const v2f bax = bx - ax, bay = by - ay;
+  const v2f l2 = bax * bax + bay * bay;
+  const v2f num = bax * (px - ax) + bay * (py - ay);
+  v2f r0;
+  r0.x = __builtin_amdgcn_rcpf(l2.x); r0.y = __builtin_amdgcn_rcpf(l2.y);
+  const v2f one = {1.0f, 1.0f};
+  const v2f r = fma2(fma2(-l2, r0, one), r0, r0);
+  v2f t = num * r;
+  t = fma2(fma2(-l2, t, num), r, t);
+  t = fma2(fma2(-l2, t, num), r, t);
+  t.x = fminf(fmaxf(t.x, 0.0f), 1.0f); t.y = fminf(fmaxf(t.y, 0.0f), 1.0f);
+  const v2f qx = ax + t * bax, qy = ay + t * bay;
+  const v2f dx = qx - px, dy = qy - py;
+  v2f d = dx * dx + dy * dy;
+  const v2f ex = px - bx, ey = py - by;       // degenerate segment (l2 <= kEps): distance to b
+  const v2f de = ex * ex + ey * ey;
+  d.x = l2.x <= ACFM_K_EPS ? de.x : d.x;
+  d.y = l2.y <= ACFM_K_EPS ? de.y : d.y;
+  return d;
 }
 
 // PixToNdc

@@ -123,8 +123,9 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
       bx0 = fminf(bx0, b.x); bx1 = fmaxf(bx1, b.y); by0 = fminf(by0, b.z); by1 = fmaxf(by1, b.w);
     }
     const size_t o = (size_t)n * F + f;
-    ws.recA[o] = make_float4(x0, y0, x1, y1);
-    ws.recB[o] = make_float4(x2, y2, z0, z1);
+    // (x1, x2) and (y1, y2) sit in aligned register pairs after the 16-byte LDS reads: operands of the packed fp32 pipe
+    ws.recA[o] = make_float4(x0, y0, x1, x2);
+    ws.recB[o] = make_float4(y1, y2, z0, z1);
     ws.recC[o] = make_float4(z2, area, 0.f, 0.f);
     ws.box[o] = b;
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
@@ -415,7 +416,7 @@ __device__ __forceinline__ Cand load_cand(const CandList& L, int i) {
 // above the rounding of the per-pixel distance.  bit0 x0y0, bit1 x1y0, bit2 x0y1, bit3 x1y1.
 __device__ __forceinline__ unsigned edge_cull4(const float4 a, const float4 b, float cx0, float cx1,
                                                float cy0, float cy1, float hx, float hy, float r) {
-  const float px[3] = {a.x, a.z, b.x}, py[3] = {a.y, a.w, b.y};
+  const float px[3] = {a.x, a.z, a.w}, py[3] = {a.y, b.x, b.y};
   unsigned out = 0u;
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
@@ -664,7 +665,7 @@ struct Hit { float pz, sd, c0, c1, c2, d01, d02, d12; };
 template <bool CLIP>
 __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4& A, const float4& B,
                                                 float z2, float area, Hit& h, bool& inside) {
-  const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
+  const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
   const float z0 = B.z, z1 = B.w;
   const float denom = area + ACFM_K_EPS;
   // three IEEE divisions by the same denominator share one refined reciprocal (acfm_common.h)
@@ -690,9 +691,12 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
 
 __device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4& A, const float4& B,
                                                float blur, bool inside, Hit& h) {
-  const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
-  h.d01 = point_line_dist(xf, yf, x0, y0, x1, y1);
-  h.d02 = point_line_dist(xf, yf, x0, y0, x2, y2);
+  const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
+  // edges 01 and 02 (both start at vertex 0) share the packed pipe, edge 12 goes through the scalar one
+  const v2f ax = {x0, x0}, ay = {y0, y0}, bx = {A.z, A.w}, by = {B.x, B.y};
+  const v2f d2 = point_line_dist2(xf, yf, ax, ay, bx, by);
+  h.d01 = d2.x;
+  h.d02 = d2.y;
   h.d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
   const float d = fminf(fminf(h.d01, h.d02), h.d12);
   h.sd = inside ? -d : d;
@@ -1097,7 +1101,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
       if (member) {
-        const float x0 = A.x, y0 = A.y, x1 = A.z, y1 = A.w, x2 = B.x, y2 = B.y;
+        const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
         // inside <=> sd < 0: an inside pixel lies on no edge, so d > 0 and sd = -d < 0
         const bool inside = h.sd < 0.0f;
         const float gs = coef * sigmoid_neg(h.sd, sigma);   // dL / d sd
