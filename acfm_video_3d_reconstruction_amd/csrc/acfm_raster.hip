@@ -662,7 +662,9 @@ struct Hit { float pz, sd, c0, c1, c2, d01, d02, d12; };
 // them in a different order keeps the accepted set -- and every accepted value -- identical.
 //   stage 1: barycentrics (IEEE divisions), depth pz, inside flag;  rejects pz < 0
 //   stage 2: the three edge distances;  rejects !inside && d >= blur
-template <bool CLIP>
+// INSIDE_ONLY: the caller keeps only pixels inside the face (blur == 0): the others leave before
+// the clipped barycentrics and the depth are computed.
+template <bool CLIP, bool INSIDE_ONLY = false>
 __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4& A, const float4& B,
                                                 float z2, float area, Hit& h, bool& inside) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
@@ -675,6 +677,8 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
   const float w1 = div(edge_fn(xf, yf, x2, y2, x0, y0));
   const float w2 = div(edge_fn(xf, yf, x0, y0, x1, y1));
   float c0 = w0, c1 = w1, c2 = w2;
+  inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  if (INSIDE_ONLY && !inside) return false;
   if (CLIP) {
     c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
     c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
@@ -684,7 +688,6 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
     c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
   }
   const float pz = c0 * z0 + c1 * z1 + c2 * z2;
-  inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
   h.pz = pz; h.c0 = c0; h.c1 = c1; h.c2 = c2;
   return !(pz < 0.0f);
 }
@@ -825,11 +828,22 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
   if constexpr (K == 1) {
     unsigned long long bestkey = KEY_NONE;
     float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
+    // blur == 0 (every hard render of the reference): a face is accepted iff the pixel is inside it,
+    // so the three edge distances decide nothing; only the winner's signed distance is ever used
+    // (the blend weight of the texture branch) and is evaluated once per pixel after the walk.
+    const bool dist_late = !(blur > 0.0f);
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
         Hit h;
-        if (!test_face<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, blur, h)) return;
+        h.sd = 0.f;
+        bool inside = false;
+        if (dist_late) {
+          if (!test_face_depth<CLIP, true>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+        } else {
+          if (!test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+          if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
+        }
         const unsigned long long key = make_key(h.pz, cd.fid);
         if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
       });
@@ -837,6 +851,12 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     if (!t.valid) return;
     const bool hit = (bestkey != KEY_NONE);
     const int f = (int)(bestkey & 0xffffffffu);
+    if (TEX && dist_late && hit) {
+      const size_t o = (size_t)n * F + f;
+      Hit h;
+      test_face_dist(t.xf, t.yf, ws.recA[o], ws.recB[o], 0.0f, true, h);
+      bestsd = h.sd;
+    }
     out.p2f[t.pix] = hit ? fbase + f : (int64_t)-1;
     if (out.vis && hit) mark_visible(ws, out, n, F, f);
     if (TEX) {
