@@ -231,28 +231,59 @@ __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int
   return ws.tile_cnt[((size_t)n * tiles + by * RBLK / CNT_TILE) * tiles + bx * RBLK / CNT_TILE];
 }
 __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int H, int g_split_dev) {
-  __shared__ int s_hist[NCLASS], s_base[NCLASS], s_split;
-  const int G = gridDim.x, g = blockIdx.x, lane = threadIdx.x & 63;
+  // counting sort by cost class without atomics: every wave counts its entries per class (ballots,
+  // wave-uniform counters), the counts are prefix-summed over (class, wave), and every wave then
+  // scatters its entries from its own running offsets.  Deterministic order.
+  constexpr int NW = 16;   // waves of the workgroup
+  __shared__ int s_cnt[NCLASS][NW], s_off[NCLASS][NW], s_hist[NCLASS], s_split;
+  const int G = gridDim.x, g = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int per = (N / G) * tt;
-  if (threadIdx.x < NCLASS) s_hist[threadIdx.x] = 0;
-  __syncthreads();
   const int iters = (per + (int)blockDim.x - 1) / (int)blockDim.x;
-  // pass 1: class histogram (one LDS atomic per wave and class)
-  for (int it = 0; it < iters; ++it) {
-    const int e = it * blockDim.x + threadIdx.x;
-    int cls = -1;
-    if (e < per) cls = cost_class(block_cost(ws, (e / tt) * G + g, e % tt, H));
+  // entry e = m tt + bl  <->  mesh m G + g, block bl; its cost is tile_cnt[mesh][bl] (CNT_TILE == RBLK).
+  // (m, bl) advance with e: no integer divisions in the loops (they were 2000 VALU instructions per wave).
+  static_assert(CNT_TILE == RBLK, "cost counters are per raster block");
+  const int m_first = (int)threadIdx.x / tt, bl_first = (int)threadIdx.x % tt;
+  constexpr int OCH = 8;   // entries per thread whose cost loads are in flight together
+  int cnt[NCLASS];
 #pragma unroll
-    for (int c = 0; c < NCLASS; ++c) {
-      const unsigned long long m = __ballot(cls == c);
-      if (m != 0ull && lane == (int)__ffsll((long long)m) - 1) atomicAdd(&s_hist[c], __popcll(m));
+  for (int c = 0; c < NCLASS; ++c) cnt[c] = 0;
+  int m1 = m_first, bl1 = bl_first;
+  for (int it0 = 0; it0 < iters; it0 += OCH) {
+    int cst[OCH];
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) {
+      const int e = (it0 + u) * blockDim.x + threadIdx.x;
+      cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
+      bl1 += blockDim.x;
+      while (bl1 >= tt) { bl1 -= tt; ++m1; }
+    }
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) {
+      const int cl = cst[u] < 0 ? -1 : cost_class(cst[u]);
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) cnt[c] += __popcll(__ballot(cl == c));
     }
   }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) s_cnt[c][wv] = cnt[c];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < NCLASS) {   // per class: total, then (below) the offsets of the waves inside the class
+    int t = 0;
+    for (int w = 0; w < NW; ++w) t += s_cnt[threadIdx.x][w];
+    s_hist[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NCLASS) {
     int acc = 0;
-    for (int c = 0; c < NCLASS; ++c) { s_base[c] = acc; acc += s_hist[c]; }
-    ws.n_work[g] = s_base[NCLASS - 1];   // the flagged-empty class sits at the end of the order
+    for (int c = 0; c < (int)threadIdx.x; ++c) acc += s_hist[c];
+    for (int w = 0; w < NW; ++w) { s_off[threadIdx.x][w] = acc; acc += s_cnt[threadIdx.x][w]; }
+  }
+  if (threadIdx.x == 0) {
+    int nw = 0;
+    for (int c = 0; c < NCLASS - 1; ++c) nw += s_hist[c];
+    ws.n_work[g] = nw;   // the flagged-empty class sits at the end of the order
     // Split the heaviest blocks over four workgroups each?  It adds ~25 % work to those blocks and
     // shortens the longest one about 3x: worth it while the group's longest block (in candidate
     // faces ~ walk iterations) outweighs its total work spread over the XCD's 384 wave slots.
@@ -270,22 +301,33 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
   __syncthreads();
   const int split_slots = s_split ? ws.split_slots : 0;
   // pass 2: scatter (order inside a class is arbitrary: results never depend on it)
-  int* ord = ws.order + (size_t)g * per;
-  for (int it = 0; it < iters; ++it) {
-    const int e = it * blockDim.x + threadIdx.x;
-    int cls = -1;
-    if (e < per) cls = cost_class(block_cost(ws, (e / tt) * G + g, e % tt, H));
+  int off[NCLASS];
 #pragma unroll
-    for (int c = 0; c < NCLASS; ++c) {
-      const unsigned long long m = __ballot(cls == c);
-      if (m == 0ull) continue;
-      const int leader = (int)__ffsll((long long)m) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&s_base[c], __popcll(m));
-      base = __shfl(base, leader, 64);
-      if (cls == c) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        ord[pos] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0) | ((c <= SPLIT_MAX_CLASS && pos < split_slots) ? ENTRY_SPLIT : 0);
+  for (int c = 0; c < NCLASS; ++c) off[c] = s_off[c][wv];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int* ord = ws.order + (size_t)g * per;
+  m1 = m_first; bl1 = bl_first;
+  for (int it0 = 0; it0 < iters; it0 += OCH) {
+    int cst[OCH];
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) {
+      const int e = (it0 + u) * blockDim.x + threadIdx.x;
+      cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
+      bl1 += blockDim.x;
+      while (bl1 >= tt) { bl1 -= tt; ++m1; }
+    }
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) {
+      const int e = (it0 + u) * blockDim.x + threadIdx.x;
+      const int cls = cst[u] < 0 ? -1 : cost_class(cst[u]);
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) {
+          const int pos = off[c] + __popcll(m & lt);
+          ord[pos] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0) | ((c <= SPLIT_MAX_CLASS && pos < split_slots) ? ENTRY_SPLIT : 0);
+        }
+        off[c] += __popcll(m);
       }
     }
   }

@@ -54,7 +54,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self._zero()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.aux = self._one(zero=False)
             self.grads = {k: self.static[k].grad for k in self.grad_inputs}
         with torch.no_grad():                 # undo the warm-up: same tensors, original values

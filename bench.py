@@ -185,7 +185,8 @@ def main():
                 compute(ren)
         cur.wait_stream(s2)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             outs = compute(ren)
 
         def replay(_ren=None):
@@ -200,9 +201,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graph_note = []
+
     def timed(ren, warmup, steps, use_graph=None):
         use_graph = (not a.eager and side is None) if use_graph is None else use_graph
-        fn = graphed(ren) if use_graph else step
+        fn = step
+        if use_graph:
+            try:
+                fn = graphed(ren)
+            except Exception as exc:   # never lose the measurement to a capture problem: fall back, and say so
+                torch.cuda.synchronize()
+                graph_note.append("capture failed (%s: %s), eager launch instead" % (type(exc).__name__, str(exc)[:200]))
         for _ in range(warmup):
             fn(ren)
         fence()
@@ -315,6 +324,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
         }
         out["launch"] = "one hipGraph replay per step (+ the RCCL all-reduce)" if use_graph else "eager (one Python launch per kernel)"
+        if graph_note:
+            out["launch_note"] = graph_note
         if dt_other:
             out["hipgraph_replay" if not use_graph else "eager_launch"] = {
                 "value": round(world * N * a.steps / dt_other, 2), "unit": "frames/s",

@@ -5,6 +5,6 @@ timeout -k 10 300 python bench.py --no-cpu --no-lean > gpurun_out/b8.json 2> gpu
 python - <<'PY'
 import json
 j = json.load(open("gpurun_out/b8.json"))
-print(j["value"], j["ms_per_step"], j.get("eager_launch"))
+print(j["value"], j["ms_per_step"], j.get("eager_launch"), j.get("launch_note"))
 print({k: round(v["us_per_step"], 1) for k, v in j["kernels"].items()})
 PY
