@@ -7,7 +7,7 @@
 namespace acfm {
 
 constexpr int LTPB = 256;
-constexpr int PIX_PER_BLOCK = 4096;  // 16 px per thread: 4 x float4
+constexpr int PIX_PER_BLOCK = 2048;  // 8 px per thread: 2 x float4
 
 // out[n] += (sum|m-gt|/HW, sum m*gt, sum(m+gt-m*gt), sum edt*m/HW); one pass over the mask.
 // (prediction n is compared with reference n % RB: the G camera hypotheses of a frame share the
@@ -64,11 +64,25 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses_bwd(const float* __restric
   const float g0 = go[4 * n] * inv, g1 = go[4 * n + 1], g2 = go[4 * n + 2], g3 = go[4 * n + 3] * inv;
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
-  for (int i = start + threadIdx.x; i < end; i += LTPB) {
-    const float m = mask[base + i], g = gt ? gt[rbase + i] : 0.f, e = edt ? edt[rbase + i] : 0.f;
+  auto one = [&](float m, float g, float e) {
     const float df = m - g;
     const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-    grad_mask[base + i] = g0 * sgn + g1 * g + g2 * (1.0f - g) + g3 * e;
+    return g0 * sgn + g1 * g + g2 * (1.0f - g) + g3 * e;
+  };
+  if ((HW & 3) == 0) {   // 16-byte loads and stores
+    for (int i = start + threadIdx.x * 4; i < end; i += LTPB * 4) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + base + i);
+      float4 g = make_float4(0, 0, 0, 0), e = make_float4(0, 0, 0, 0);
+      if (gt) g = *reinterpret_cast<const float4*>(gt + rbase + i);
+      if (edt) e = *reinterpret_cast<const float4*>(edt + rbase + i);
+      *reinterpret_cast<float4*>(grad_mask + base + i) =
+          make_float4(one(m.x, g.x, e.x), one(m.y, g.y, e.y), one(m.z, g.z, e.z), one(m.w, g.w, e.w));
+    }
+    return;
+  }
+  for (int i = start + threadIdx.x; i < end; i += LTPB) {
+    const float m = mask[base + i], g = gt ? gt[rbase + i] : 0.f, e = edt ? edt[rbase + i] : 0.f;
+    grad_mask[base + i] = one(m, g, e);
   }
 }
 
@@ -84,6 +98,19 @@ __global__ __launch_bounds__(LTPB) void k_tex_mse(const float* __restrict__ tex,
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
   float acc = 0.f;
+  if ((HW & 3) == 0) {   // 16-byte loads
+    for (int i = start + tid * 4; i < end; i += LTPB * 4) {
+      const float4 mk = *reinterpret_cast<const float4*>(m + b1 + i);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(tex + b3 + (size_t)c * HW + i);
+        const float4 g = *reinterpret_cast<const float4*>(img + r3 + (size_t)c * HW + i);
+        const float d0 = t.x * mk.x - g.x * mk.x, d1 = t.y * mk.y - g.y * mk.y;
+        const float d2 = t.z * mk.z - g.z * mk.z, d3 = t.w * mk.w - g.w * mk.w;
+        acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+    }
+  } else
   for (int i = start + tid; i < end; i += LTPB) {
     const float mk = m[b1 + i];
 #pragma unroll
@@ -108,6 +135,21 @@ __global__ __launch_bounds__(LTPB) void k_tex_mse_bwd(const float* __restrict__ 
   const float w = go[n] * 2.0f / (3.0f * (float)HW);
   const int start = blockIdx.x * PIX_PER_BLOCK;
   const int end = min(start + PIX_PER_BLOCK, HW);
+  if ((HW & 3) == 0) {   // 16-byte loads and stores
+    for (int i = start + threadIdx.x * 4; i < end; i += LTPB * 4) {
+      const float4 mk = *reinterpret_cast<const float4*>(m + b1 + i);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = b3 + (size_t)c * HW + i;
+        const float4 t = *reinterpret_cast<const float4*>(tex + o);
+        const float4 g = *reinterpret_cast<const float4*>(img + r3 + (size_t)c * HW + i);
+        *reinterpret_cast<float4*>(gtex + o) =
+            make_float4(w * (t.x * mk.x - g.x * mk.x) * mk.x, w * (t.y * mk.y - g.y * mk.y) * mk.y,
+                        w * (t.z * mk.z - g.z * mk.z) * mk.z, w * (t.w * mk.w - g.w * mk.w) * mk.w);
+      }
+    }
+    return;
+  }
   for (int i = start + threadIdx.x; i < end; i += LTPB) {
     const float mk = m[b1 + i];
 #pragma unroll

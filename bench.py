@@ -273,18 +273,28 @@ def main():
         ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
         # the committed measurement of the same workload (rocprofv3 --pmc, separate passes) is quoted
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             w = pm["workload"]
             if (w["frames"], w["img"], w["K"]) == (N, H, 20) and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom]["fetch_bytes"] + pm["kernels"][dom]["write_bytes"]
                 traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch)"
+                valu_insts = pm["kernels"][dom].get("valu_insts")
         except (OSError, KeyError, ValueError):
             pass
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
+        if valu_insts:
+            # The kernel is bound by VALU issue, not by HBM: a wave64 VALU instruction occupies its SIMD
+            # for 4 cycles, 1024 SIMDs at 2.4 GHz issue 614 G of them per second (MI355X_MICROARCH.md).
+            # SQ_INSTS_VALU per launch from the committed PMC pass of the same workload.
+            peak = 1024 * 2.4e9 / 4
+            rate = valu_insts / (kern[dom]["avg_us"] * 1e-6)
+            roof["valu"] = dict(insts_per_launch=valu_insts, achieved_ginst_s=round(rate / 1e9, 1),
+                                peak_ginst_s=round(peak / 1e9, 1), frac=round(rate / peak, 4),
+                                source="profiles/r01_pmc_traffic.json (SQ_INSTS_VALU, own --pmc pass)")
         if traffic:   # what the kernel actually moves (the API's K int64 ids per pixel dominate): context, not `achieved`
             moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))

@@ -12,7 +12,7 @@ tools/pmc.sh $o/pmc_sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES
 tools/pmc.sh $o/pmc_f FETCH_SIZE -- --iters 3 > $o/${tag}_pmc_hbm.txt 2>&1 || exit 1
 tools/pmc.sh $o/pmc_w WRITE_SIZE -- --iters 3 >> $o/${tag}_pmc_hbm.txt 2>&1 || exit 1
 (for n in 8 64; do for m in sil tex; do echo "== frames $n kernel $m"; python tools/stamps.py $n $m | grep -E "span|slots|start time|bin_us|^ +[0-9]+ +[0-9]+ +[0-9]+ "; done; done) > $o/${tag}_tile_stamps.txt 2>&1
-python tools/pmc_traffic.py $o/${tag}_pmc_hbm.txt > $o/${tag}_pmc_traffic.json
+python tools/pmc_traffic.py $o/${tag}_pmc_hbm.txt $o/${tag}_pmc_sq.txt > $o/${tag}_pmc_traffic.json
 # the callers either side of the render path: multiframe training step (eager / one hipGraph) and
 # the per-step deformation solve (native fp64 Cholesky vs torch.linalg)
 (python tools/step_bench.py; python tools/step_bench.py --graph; python tools/solve_bench.py; python tools/refine_bench.py) > $o/${tag}_step_solve_refine.txt 2>&1
