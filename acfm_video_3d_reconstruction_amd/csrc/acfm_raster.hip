@@ -45,6 +45,7 @@ constexpr int ENTRY_FLAGS = ENTRY_EMPTY | ENTRY_SPLIT;
 constexpr int SPLIT_MAX_CLASS = 2;     // ... if their cost class is at most this (>= 80 face boxes)
 constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
+typedef unsigned short fl_t;  // face ids of one mesh (F <= ACFM_MAX_FACES = 65535)
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
 
 // ------------------------------------------------------------------------------- setup
@@ -432,12 +433,15 @@ __device__ __forceinline__ Tile make_tile(const RasterWs& ws, const Sched& s, in
   return t;
 }
 
-struct CandList {
-  float4 box[RCAP], a[RCAP], b[RCAP];
-  float2 c[RCAP];    // (z2, area)
-  int fid[RCAP];
-  unsigned short sub[4][RCAP]; // per 16-lane group: candidates meeting its 4x4 pixels
+template <int CAP_>
+struct CandListT {
+  static constexpr int CAP = CAP_;
+  float4 box[CAP_], a[CAP_], b[CAP_];
+  float2 c[CAP_];    // (z2, area)
+  int fid[CAP_];
+  unsigned short sub[4][CAP_]; // per 16-lane group: candidates meeting its 4x4 pixels
 };
+
 
 struct Cand {
   float4 box, a, b;
@@ -445,7 +449,8 @@ struct Cand {
   int fid, idx;
 };
 
-__device__ __forceinline__ Cand load_cand(const CandList& L, int i) {
+template <class LT>
+__device__ __forceinline__ Cand load_cand(const LT& L, int i) {
   Cand r;
   r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i]; r.c = L.c[i]; r.fid = L.fid[i]; r.idx = i;
   return r;
@@ -490,8 +495,8 @@ __device__ __forceinline__ unsigned edge_cull4(const float4 a, const float4 b, f
 // EDGE_CULL pays for itself only where a kept pair is expensive (the K-nearest forward walk:
 // -4.5 %); the backward and nearest-face walks drop most pairs on a cheap key / depth compare and
 // were measured slower with it (+7 %, +2 %).
-template <bool EDGE_CULL, class Body>
-__device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int list_n, float blur,
+template <bool EDGE_CULL, class LT, class Body>
+__device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_n, float blur,
                                           unsigned short* wl /* [RCAP], EDGE_CULL only */,
                                           Body&& body) {
   const int by = (t.yi & ~7), bx = (t.xi & ~7);
@@ -521,10 +526,10 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
       }
       const unsigned long long b0 = __ballot(hx0 & hy0), b1 = __ballot(hx1 & hy0);
       const unsigned long long b2 = __ballot(hx0 & hy1), b3 = __ballot(hx1 & hy1);
-      if (hx0 & hy0) sub0[0 * RCAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (hx1 & hy0) sub0[1 * RCAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (hx0 & hy1) sub0[2 * RCAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (hx1 & hy1) sub0[3 * RCAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (hx0 & hy0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
+      if (hx1 & hy0) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
+      if (hx0 & hy1) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
+      if (hx1 & hy1) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   } else {
@@ -565,10 +570,10 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
       }
       const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
       const unsigned long long b2 = __ballot(k2), b3 = __ballot(k3);
-      if (k0) sub0[0 * RCAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (k1) sub0[1 * RCAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (k2) sub0[2 * RCAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (k3) sub0[3 * RCAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (k0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
+      if (k1) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
+      if (k2) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
+      if (k3) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   }
@@ -578,7 +583,7 @@ __device__ __forceinline__ void walk_wave(CandList& L, const Tile& t, int H, int
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int my_n = (grp == 0) ? n0 : (grp == 1) ? n1 : (grp == 2) ? n2 : n3;
-  const unsigned short* sub = sub0 + grp * RCAP;
+  const unsigned short* sub = sub0 + grp * LT::CAP;
   // a group that has run out of faces (or has none) keeps loading its last (or the tile's
   // first) record: harmless, the lanes are masked by `have`.  (Prefetching the next record one
   // iteration ahead was measured: +16 VGPRs, no change in time.)
@@ -613,9 +618,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
   return x;
 }
 
-template <class Walk>
-__device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, CandList& L,
-                                             int* s_fl /* [FLCAP] */, float box_shrink, Walk&& walk) {
+template <class LT, class Walk>
+__device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, LT& L,
+                                             fl_t* s_fl /* [FLCAP] */, float box_shrink, Walk&& walk) {
   if (t.empty) return;  // flagged by k_order: no face box near this block
   float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
 #pragma unroll
@@ -655,7 +660,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
         const int fbase = (w0 + t.lane) * 64;
 #pragma unroll 1
         while (m != 0ull) {
-          s_fl[pos++] = fbase + (int)__ffsll((long long)m) - 1;
+          s_fl[pos++] = (fl_t)(fbase + (int)__ffsll((long long)m) - 1);
           m &= m - 1ull;
         }
         wave_lds_sync();
@@ -664,7 +669,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
     if (!done) {
       int f;
       if (direct) { f = (f0 + t.lane < fe) ? f0 + t.lane : -1; f0 += RT; }
-      else { f = (i0 + t.lane < total) ? s_fl[i0 + t.lane] : -1; i0 += RT; }
+      else { f = (i0 + t.lane < total) ? (int)s_fl[i0 + t.lane] : -1; i0 += RT; }
       bool pass = false;
       float4 b = make_float4(0, 0, 0, 0);
       if (f >= 0) {
@@ -687,7 +692,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
       }
       list_n += __popcll(bal);
     }
-    if (list_n > RCAP - RT || (done && list_n > 0)) {
+    if (list_n > LT::CAP - RT || (done && list_n > 0)) {
       wave_lds_sync();
       walk(list_n);
       wave_lds_sync();
@@ -815,11 +820,19 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
   }
 }
 
-struct FwdLds {
-  CandList L;
-  int fl[FLCAP];
-  unsigned short wl[RCAP];
+// LDS of a forward workgroup (one wave).  The nearest-face kernels keep a 64-slot candidate list
+// (5.5 KB: the register budget, not LDS, then bounds the waves per SIMD -- measured on the
+// backward: 13.8 KB -> 6.9 KB per wave = 292 -> 256 us); the K-nearest kernels are register-bound
+// at 3-4 waves per SIMD anyway and need 64 K 8 bytes to stage the block's face ids.
+template <int CAP, int MIN_BYTES>
+struct FwdLdsT {
+  static constexpr int USED = (int)sizeof(CandListT<CAP>) + 2 * FLCAP + 2 * CAP;
+  CandListT<CAP> L;
+  fl_t fl[FLCAP];
+  unsigned short wl[CAP];
+  char pad[MIN_BYTES > USED ? MIN_BYTES - USED : 16];
 };
+template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? RCAP : 64), (K > 1 ? 64 * K * 8 : 0)>;
 
 // Constant outputs of a flagged-empty 8x8 block (no face box comes near it): exactly what
 // fwd_block leaves for a block without candidates.  Lane i owns pixel (i / 8, i % 8) of the block;
@@ -861,9 +874,9 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
 
 template <int K, bool CLIP, bool TEX>
 __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
-                                          const FwdOut& out, FwdLds& S) {
-  CandList& L = S.L;
-  int* s_fl = S.fl;
+                                          const FwdOut& out, FwdLdsK<K>& S) {
+  auto& L = S.L;
+  fl_t* s_fl = S.fl;
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
 
@@ -1016,7 +1029,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     if (out.kout == 1) return;
     typedef long long ll2 __attribute__((ext_vector_type(2)));  // K even -> 16-byte pieces
     constexpr int CH = K / 2;                                   // pieces per pixel
-    constexpr bool STAGED = sizeof(FwdLds) >= (size_t)64 * K * 8;
+    constexpr bool STAGED = sizeof(FwdLdsK<K>) >= (size_t)64 * K * 8;
     if (STAGED && !split) {
       // The K ids of a pixel are 8K contiguous bytes, so a lane storing its own row hits 64
       // different cache lines per instruction.  The block's ids are therefore staged in LDS (the
@@ -1058,7 +1071,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 template <int K, bool CLIP, bool TEX>
 __global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
-  __shared__ __attribute__((aligned(16))) FwdLds S;
+  __shared__ __attribute__((aligned(16))) FwdLdsK<K> S;
   const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
   struct Stamp {
     unsigned long long* p; unsigned long long t0;
@@ -1123,10 +1136,15 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
   gbx = g * t * ex; gby = g * t * ey;
 }
 
+#ifndef ACFM_BWD_CAP
+#define ACFM_BWD_CAP 64
+#endif
+constexpr int BWD_CAP = ACFM_BWD_CAP;   // candidate-list capacity of the backward (LDS per wave: 108 B per slot)
+using BwdList = CandListT<BWD_CAP>;
 __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const float* __restrict__ mask,
                                               const unsigned long long* __restrict__ kth,
                                               const float* __restrict__ grad_mask, int V, int F, int H, float blur,
-                                              float sigma, CandList& L, int* s_fl, float (*s_acc)[6]) {
+                                              float sigma, BwdList& L, fl_t* s_fl, float (*s_acc)[6]) {
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
@@ -1142,7 +1160,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   const bool work = (coef != 0.0f);
   if (__ballot(work) == 0ull) return;
 
-  for (int i = t.tid; i < RCAP * 6; i += RT) (&s_acc[0][0])[i] = 0.f;
+  for (int i = t.tid; i < BWD_CAP * 6; i += RT) (&s_acc[0][0])[i] = 0.f;
   wave_lds_sync();
   float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
 
@@ -1217,13 +1235,13 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
                                                  const unsigned long long* __restrict__ kth,
                                                  const float* __restrict__ grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {
-  __shared__ CandList L;
-  __shared__ int s_fl[FLCAP];
+  __shared__ BwdList L;
+  __shared__ fl_t s_fl[FLCAP];
   // gradient accumulator per list slot: (d/dx0, d/dy0, d/dx1, d/dy1, d/dx2, d/dy2) of that face,
   // summed over the block's pixels; flushed (global float atomics on the face's three vertices)
   // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
   // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
-  __shared__ float s_acc[RCAP][6];
+  __shared__ float s_acc[BWD_CAP][6];
   const Sched sc = make_sched(ws, N, H, true);
 #pragma unroll 1
   for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
