@@ -807,13 +807,19 @@ __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& o
 template <int K, int LO>
 __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], float (&q)[K],
                                               unsigned long long& x, float& xq, int lim) {
+  // The list is sorted, so key[HI-1] is the largest of the block: if no active lane's element is
+  // smaller, nothing moves in these four slots (the new face lies deeper than all of them in every
+  // lane -- faces arrive in id order, not in depth order) and the block costs one compare.
+  constexpr int HI = (LO + 4 < K ? LO + 4 : K);
+  if (__ballot(x < key[HI - 1]) != 0ull) {
 #pragma unroll
-  for (int k = LO; k < (LO + 4 < K ? LO + 4 : K); ++k) {
-    const bool sw = x < key[k];
-    const unsigned long long tk = key[k];
-    const float tq = q[k];
-    key[k] = sw ? x : tk; x = sw ? tk : x;
-    q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
+    for (int k = LO; k < HI; ++k) {
+      const bool sw = x < key[k];
+      const unsigned long long tk = key[k];
+      const float tq = q[k];
+      key[k] = sw ? x : tk; x = sw ? tk : x;
+      q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
+    }
   }
   if constexpr (LO + 4 < K) {
     if (lim > LO + 4) bubble_insert<K, LO + 4>(key, q, x, xq, lim);
@@ -1069,7 +1075,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 }
 
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(RT, K > 20 ? 2 : K > 10 ? 3 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+__global__ __launch_bounds__(RT, K > 20 ? 2 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
   __shared__ __attribute__((aligned(16))) FwdLdsK<K> S;
   const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
