@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 }
 
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(RT, K > 20 ? 2 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+__global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? 6 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
   __shared__ __attribute__((aligned(16))) FwdLdsK<K> S;
   const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
