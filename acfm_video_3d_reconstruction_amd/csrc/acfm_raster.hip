@@ -550,6 +550,38 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (A1') front to back, roughly: the wave's list is dealt into 8 depth classes (nearest vertex of
+    // the face, classes between the block's nearest and farthest) by a counting sort with ballots.
+    // Results never depend on the order of the candidates, the cost of the walk does: a face that
+    // arrives after the nearer ones enters a pixel's sorted list near its end, the bubble insertion
+    // skips the leading 4-slot blocks it cannot touch, and once a list is full the faces behind it
+    // fail the depth test before their edge distances are computed.
+    if (nw > 8) {
+      static_assert(LT::CAP <= 128, "two list entries per lane");
+      const int i0 = t.lane, i1 = t.lane + 64;
+      const int c0 = i0 < nw ? (int)wl[i0] : 0, c1 = i1 < nw ? (int)wl[i1] : 0;
+      const float INF = __builtin_inff();
+      const float z0 = i0 < nw ? min3f(L.b[c0].z, L.b[c0].w, L.c[c0].x) : INF;
+      const float z1 = i1 < nw ? min3f(L.b[c1].z, L.b[c1].w, L.c[c1].x) : INF;
+      const float zlo = wave_min(fminf(z0, z1));
+      const float zhi = wave_max(fmaxf(i0 < nw ? z0 : -INF, i1 < nw ? z1 : -INF));
+      const float sc = 8.0f / fmaxf(zhi - zlo, 1e-12f);
+      const int b0 = i0 < nw ? min(7, (int)((z0 - zlo) * sc)) : -1;
+      const int b1 = i1 < nw ? min(7, (int)((z1 - zlo) * sc)) : -1;
+      unsigned short* wl2 = wl + LT::CAP;
+      int base = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned long long m0 = __ballot(b0 == c), m1 = __ballot(b1 == c);
+        if (b0 == c) wl2[base + __popcll(m0 & lt)] = (unsigned short)c0;
+        if (b1 == c) wl2[base + __popcll(m0) + __popcll(m1 & lt)] = (unsigned short)c1;
+        base += __popcll(m0) + __popcll(m1);
+      }
+      wl = wl2;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     // (A2) per 4x4 block: box, then the edge-line test
     const float cx0 = 0.5f * (xa0 + xi0), cx1 = 0.5f * (xa1 + xi1);
     const float cy0 = 0.5f * (ya0 + yi0), cy1 = 0.5f * (ya1 + yi1);
@@ -832,11 +864,15 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
 // at 3-4 waves per SIMD anyway and need 64 K 8 bytes to stage the block's face ids.
 template <int CAP, int MIN_BYTES>
 struct FwdLdsT {
-  static constexpr int USED = (int)sizeof(CandListT<CAP>) + 2 * FLCAP + 2 * CAP;
-  CandListT<CAP> L;
-  fl_t fl[FLCAP];
-  unsigned short wl[CAP];
-  char pad[MIN_BYTES > USED ? MIN_BYTES - USED : 16];
+  struct Lists {
+    CandListT<CAP> L;
+    fl_t fl[FLCAP];
+    unsigned short wl[2 * CAP];   // the wave's list of the edge cull, and the same in depth order
+  };
+  union {
+    Lists s;
+    char stage[MIN_BYTES > 16 ? MIN_BYTES : 16];   // the block's K ids in image order (the lists are dead by then)
+  };
 };
 template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? RCAP : 64), (K > 1 ? 64 * K * 8 : 0)>;
 
@@ -881,8 +917,8 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
 template <int K, bool CLIP, bool TEX>
 __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
                                           const FwdOut& out, FwdLdsK<K>& S) {
-  auto& L = S.L;
-  fl_t* s_fl = S.fl;
+  auto& L = S.s.L;
+  fl_t* s_fl = S.s.fl;
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
 
@@ -972,14 +1008,20 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     // registers.  A new face is bubbled through the array with compare-exchanges on static
     // register indices (the displaced farthest entry falls off the end), so there is no LDS or
     // memory list, no final sort and the kept set is exactly the K nearest at every moment.
-    unsigned short* s_wl = S.wl;  // first stage of the edge cull
+    unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
     unsigned long long key[K];
     float q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
+#ifdef ACFM_DIAG_NO_WALK
+      if (list_n >= 0) { seen += list_n; return; }
+#endif
       walk_wave<true>(L, t, H, list_n, blur, s_wl, [&](const Cand& cd, bool in_box, int ord) {
+#ifdef ACFM_DIAG_NO_BODY
+        if (ord >= 0) return;
+#endif
         // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list
         // cannot enter it; when that holds for every lane of the wave the face is dropped
         // before its edge distances are computed (empty slots hold ~0, so x < key[K-1] is
@@ -992,9 +1034,17 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         live = live && (x < key[K - 1]);
         if (__ballot(live) == 0ull) return;
         if (!live) return;
+#ifdef ACFM_DIAG_NO_STAGE2
+        h.sd = h.pz;
+#else
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
+#endif
         float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma);
+#ifdef ACFM_DIAG_NO_INSERT
+        if (x < key[0]) { key[0] = x; q[0] = xq; }
+#else
         bubble_insert<K, 0>(key, q, x, xq, __builtin_amdgcn_readfirstlane(seen + ord + 1));
+#endif
       });
       seen += list_n;
     });
@@ -1042,7 +1092,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       // candidate lists are dead by now) in image order -- 8 rows of 64K contiguous bytes -- and
       // written out with consecutive lanes on consecutive 16-byte pieces.
       wave_lds_sync();
-      ll2* so = reinterpret_cast<ll2*>(&S);
+      ll2* so = reinterpret_cast<ll2*>(&S.stage[0]);
       const int slot = (t.yi & 7) * 8 + (t.xi & 7);
 #pragma unroll
       for (int k2 = 0; k2 < CH; ++k2) {

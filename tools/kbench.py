@@ -23,6 +23,7 @@ def main():
     p.add_argument("--iters", type=int, default=20)
     p.add_argument("--mesh", default="bird")
     p.add_argument("--what", default="sil,tex,loss")
+    p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
     a = p.parse_args()
     dev = torch.device("cuda:0")
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
@@ -45,7 +46,7 @@ def main():
 
     def run():
         if "sil" in a.what:
-            mask, p2f = ops.sil_render(verts, faces, cams, H)
+            mask, p2f = ops.sil_render(verts, faces, cams, H, k_out=(1 if a.kout == 1 else None))
             if "loss" in a.what:
                 l1, iou, e = L.fused_silhouette_losses(mask, gt, edt)
                 proj = ops.project(verts, cams)[..., :2]
