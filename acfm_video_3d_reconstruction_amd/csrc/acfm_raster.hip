@@ -1240,19 +1240,20 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
         // inside <=> sd < 0: an inside pixel lies on no edge, so d > 0 and sd = -d < 0
         const bool inside = h.sd < 0.0f;
-        const float gs = coef * sigmoid_neg(h.sd, sigma);   // dL / d sd
-        const float gd = inside ? -gs : gs;                 // sd = inside ? -d : d
+        // (1-ulp reciprocal in the sigmoid: 1e-7 relative on a gradient checked to 1e-4)
+        const float gs = coef * sigmoid_neg_fast(h.sd, sigma);   // dL / d sd
+        const float gd = inside ? -gs : gs;                      // sd = inside ? -d : d
+        // the arg-min edge (01 first, then 02, then 12: SURVEY App-A.4), chosen with selects so that the
+        // wave runs ONE distance backward instead of up to three divergent copies of it
+        const bool e01 = h.d01 <= h.d02 && h.d01 <= h.d12;
+        const bool e02 = !e01 && h.d02 <= h.d01 && h.d02 <= h.d12;
+        const float ax = (e01 || e02) ? x0 : x1, ay = (e01 || e02) ? y0 : y1;
+        const float bx = e01 ? x1 : x2, by = e01 ? y1 : y2;
         float ax_, ay_, bx_, by_;
-        if (h.d01 <= h.d02 && h.d01 <= h.d12) {
-          point_line_dist_bwd(t.xf, t.yf, x0, y0, x1, y1, gd, ax_, ay_, bx_, by_);
-          g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_;
-        } else if (h.d02 <= h.d01 && h.d02 <= h.d12) {
-          point_line_dist_bwd(t.xf, t.yf, x0, y0, x2, y2, gd, ax_, ay_, bx_, by_);
-          g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_;
-        } else {
-          point_line_dist_bwd(t.xf, t.yf, x1, y1, x2, y2, gd, ax_, ay_, bx_, by_);
-          g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_;
-        }
+        point_line_dist_bwd(t.xf, t.yf, ax, ay, bx, by, gd, ax_, ay_, bx_, by_);
+        if (e01) { g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_; }
+        else if (e02) { g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_; }
+        else { g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_; }
       }
       // the 16 lanes of a row share the face: sum their contributions, lane 15 of the row adds
       g0x = row_sum_dpp(g0x); g0y = row_sum_dpp(g0y);
