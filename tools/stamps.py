@@ -37,7 +37,9 @@ xcc = hw >> 32
 cu = (hw & 0xffffffff)
 print("blocks", nb, "kernel span %.1f us" % span, "block dur: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (
     dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
-print("sum of block durations %.0f us -> /3072 wave slots (3 per SIMD) = %.1f us" % (dur.sum(), dur.sum() / 3072))
+wpc = raw.acfm_debug_occupancy(0 if mode == "sil" else 1, 0)          # resident one-wave workgroups per CU
+slots = wpc * torch.cuda.get_device_properties(0).multi_processor_count
+print("sum of block durations %.0f us -> /%d wave slots (%d per CU) = %.1f us" % (dur.sum(), slots, wpc, dur.sum() / slots))
 start = (t0 - t0.min()) / 100.0
 print("start time percentiles (us): p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(start, [10, 50, 90, 100])))
 for x in range(8):
@@ -46,7 +48,7 @@ for x in range(8):
         grp = sorted(set((np.nonzero(sel)[0] & 7).tolist()))
         print("xcc", x, "blocks", sel.sum(), "block%8 groups", grp,
               "last end %.1f" % ((t1[sel].max() - t0.min()) / 100.0), "sum dur %.0f" % dur[sel].sum(),
-              "idle-weighted util %.2f" % (dur[sel].sum() / (384 * (t1[sel].max() - t0[sel].min()) / 100.0)))
+              "idle-weighted util %.2f" % (dur[sel].sum() / (slots / 8 * (t1[sel].max() - t0[sel].min()) / 100.0)))
 order = np.argsort(-dur)[:8]
 print("heaviest blocks:", [(int(i), round(float(dur[i]), 1), round(float(start[i]), 1)) for i in order])
 
