@@ -35,13 +35,18 @@ struct ProfScope {
   ~ProfScope() { prof_end(st); }
 };
 
+// Per-face record of the raster workspace (k_setup writes it, the binning of the raster kernels reads it).
+struct __attribute__((aligned(64))) FaceRec {
+  float4 box;   // (xmin,xmax,ymin,ymax), blur margin included; degenerate face = (inf,-inf,inf,-inf)
+  float4 a;     // (x0,y0,x1,x2)   -- (x1,x2), (y1,y2) as register pairs for the packed fp32 pipe
+  float4 b;     // (y1,y2,z0,z1)
+  float4 c;     // (z2, area, -, -)
+};
+
 // Workspace carve-up shared by every raster entry point (acfm_raster_workspace_bytes).
 struct RasterWs {
   float* ndc;      // [N,V,3] NDC x, NDC y, view z
-  float4* recA;    // [N,F] (x0,y0,x1,x2)
-  float4* recB;    // [N,F] (y1,y2,z0,z1)
-  float4* recC;    // [N,F] (z2, area, -, -)
-  float4* box;     // [N,F] (xmin,xmax,ymin,ymax), blur margin included; degenerate = (inf,-inf,inf,-inf)
+  FaceRec* rec;    // [N,F] one 64-byte record per face: the box test and the copy of a passing face touch ONE cache line
   int4* vidx;      // [N,F] (i0,i1,i2,-)
   float4* mbox;    // [N,4] union of the face boxes of each of the 4 face slices of k_setup
   float* grad_ndc; // [N,V,2]
@@ -74,10 +79,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
   char* p = (char*)base;
   size_t o = 0;
   w.ndc = (float*)(p + o);      o += align256(sizeof(float) * 3 * (size_t)N * V);
-  w.recA = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
-  w.recB = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
-  w.recC = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)N * F);
-  w.box = (float4*)(p + o);     o += align256(sizeof(float4) * (size_t)N * F);
+  w.rec = (FaceRec*)(p + o);    o += align256(sizeof(FaceRec) * (size_t)N * F);
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
   w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * 4 * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);

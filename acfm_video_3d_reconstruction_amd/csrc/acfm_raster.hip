@@ -125,10 +125,11 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     }
     const size_t o = (size_t)n * F + f;
     // (x1, x2) and (y1, y2) sit in aligned register pairs after the 16-byte LDS reads: operands of the packed fp32 pipe
-    ws.recA[o] = make_float4(x0, y0, x1, x2);
-    ws.recB[o] = make_float4(y1, y2, z0, z1);
-    ws.recC[o] = make_float4(z2, area, 0.f, 0.f);
-    ws.box[o] = b;
+    FaceRec& r = ws.rec[o];
+    r.box = b;
+    r.a = make_float4(x0, y0, x1, x2);
+    r.b = make_float4(y1, y2, z0, z1);
+    r.c = make_float4(z2, area, 0.f, 0.f);
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
     ws.fvis[o] = 0;
     if (!degenerate) {
@@ -705,7 +706,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
       bool pass = false;
       float4 b = make_float4(0, 0, 0, 0);
       if (f >= 0) {
-        b = ws.box[(size_t)t.n * F + f];
+        b = ws.rec[(size_t)t.n * F + f].box;
         // a workspace shared with a render of larger blur: tighten the (margin-expanded) box; a
         // degenerate face's (inf, -inf, inf, -inf) stays what it is
         b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
@@ -716,9 +717,9 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
         const int pos = list_n + __popcll(bal & lt);
         const size_t o = (size_t)t.n * F + f;
         L.box[pos] = b;
-        L.a[pos] = ws.recA[o];
-        L.b[pos] = ws.recB[o];
-        const float4 c4 = ws.recC[o];
+        L.a[pos] = ws.rec[o].a;
+        L.b[pos] = ws.rec[o].b;
+        const float4 c4 = ws.rec[o].c;
         L.c[pos] = make_float2(c4.x, c4.y);
         L.fid[pos] = f;
       }
@@ -951,7 +952,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     if (TEX && dist_late && hit) {
       const size_t o = (size_t)n * F + f;
       Hit h;
-      test_face_dist(t.xf, t.yf, ws.recA[o], ws.recB[o], 0.0f, true, h);
+      test_face_dist(t.xf, t.yf, ws.rec[o].a, ws.rec[o].b, 0.0f, true, h);
       bestsd = h.sd;
     }
     out.p2f[t.pix] = hit ? fbase + f : (int64_t)-1;
@@ -1446,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float*
     int xa = 0, ya = 0, w = 1, cnt = 0;
     const int n = a + g * NA;
     if (my_live && ws.fvis[(size_t)n * F + my_f]) {          // (a face no pixel shows has no gradient: zeros)
-      float4 b = ws.box[(size_t)n * F + my_f];
+      float4 b = ws.rec[(size_t)n * F + my_f].box;
       b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
       if (b.x <= b.y && b.z <= b.w) {                        // not a degenerate face (inf, -inf, ..) or an emptied box
         // pixel range of the box: k_setup's formula with one pixel of slack, then tightened to the
