@@ -177,38 +177,70 @@ __global__ void k_visible(const int64_t* __restrict__ p2f, const int64_t* __rest
   }
 }
 
+// One workgroup = 64 boundary points x all vertices: its four waves search a quarter of the vertices
+// each (the search is a chain of V dependent compare-selects per point: one wave per SIMD left the
+// chip idle for 20 us) and wave 0 merges the four partial minima in vertex order, so the first
+// nearest vertex wins exactly as in a single ascending scan.
 __global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ verts_xy,
                                                    const float* __restrict__ bds,
                                                    const uint8_t* __restrict__ vis, int V, int P, int RB,
                                                    float* __restrict__ loss, int32_t* __restrict__ argmin) {
   extern __shared__ float s_xy[];  // [V][2], x = +inf for invisible verts
-  __shared__ float s_red[4];
-  const int n = blockIdx.y, tid = threadIdx.x;
-  for (int v = tid; v < V; v += LTPB) {
-    const bool vz = vis[(size_t)n * V + v] != 0;
-    s_xy[2 * v] = vz ? verts_xy[((size_t)n * V + v) * 2] : __builtin_inff();
-    s_xy[2 * v + 1] = vz ? verts_xy[((size_t)n * V + v) * 2 + 1] : 0.f;
+  __shared__ float s_best[4][64];
+  __shared__ int s_bi[4][64];
+  const int n = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  // (unconditional loads, four vertices per thread in flight: with the loads behind the visibility
+  // test this fill was a chain of ~9 memory latencies and the whole kernel took 21 us)
+  for (int v0 = tid; v0 < V; v0 += 4 * LTPB) {
+    uint8_t vz[4];
+    float2 xy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = min(v0 + u * LTPB, V - 1);
+      vz[u] = vis[(size_t)n * V + v];
+      xy[u] = *reinterpret_cast<const float2*>(verts_xy + ((size_t)n * V + v) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + u * LTPB;
+      if (v < V) {
+        s_xy[2 * v] = vz[u] ? xy[u].x : __builtin_inff();
+        s_xy[2 * v + 1] = vz[u] ? xy[u].y : 0.f;
+      }
+    }
   }
   __syncthreads();
-  const int p = blockIdx.x * LTPB + tid;
-  float contrib = 0.f;
+  const int p = blockIdx.x * 64 + lane;
+  float bx = 0.f, by = 0.f, bm = 0.f;
   if (p < P) {
     const float* b = bds + ((size_t)(n % RB) * P + p) * 3;
-    const float bx = b[0], by = b[1], bm = b[2];
-    float best = 1000.0f;  // loss_utils.py:228: invisible vertices sit at distance 1000
-    int bi = -1;
-    for (int v = 0; v < V; ++v) {
-      const float dx = bx - s_xy[2 * v], dy = by - s_xy[2 * v + 1];
-      const float d = dx * dx + dy * dy;
-      if (d < best) { best = d; bi = v; }
-    }
+    bx = b[0]; by = b[1]; bm = b[2];
+  }
+  float best = 1000.0f;  // loss_utils.py:228: invisible vertices sit at distance 1000
+  int bi = -1;
+  const int chunk = (V + 3) / 4, v0 = wv * chunk, v1 = min(V, v0 + chunk);
+#pragma unroll 8
+  for (int v = v0; v < v1; ++v) {
+    const float2 q = *reinterpret_cast<const float2*>(s_xy + 2 * v);
+    const float dx = bx - q.x, dy = by - q.y;
+    const float d = dx * dx + dy * dy;
+    if (d < best) { best = d; bi = v; }
+  }
+  s_best[wv][lane] = best; s_bi[wv][lane] = bi;
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float d = s_best[w][lane];
+    if (d < best) { best = d; bi = s_bi[w][lane]; }
+  }
+  float contrib = 0.f;
+  if (p < P) {
     contrib = best * bm;
     argmin[(size_t)n * P + p] = bi;
   }
   contrib = wave_sum(contrib);
-  if ((tid & 63) == 0) s_red[tid >> 6] = contrib;
-  __syncthreads();
-  if (tid == 0) atomicAdd(&loss[n], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  if (lane == 0) atomicAdd(&loss[n], contrib);
 }
 
 __global__ void k_bds_loss_bwd(const float* __restrict__ verts_xy, const float* __restrict__ bds,
@@ -374,7 +406,7 @@ int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, i
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(loss, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_BDS, st);
-  hipLaunchKernelGGL(k_bds_loss, dim3((P + LTPB - 1) / LTPB, N), dim3(LTPB), lds, st, verts_xy, bds, vis,
+  hipLaunchKernelGGL(k_bds_loss, dim3((P + 63) / 64, N), dim3(LTPB), lds, st, verts_xy, bds, vis,
                      V, P, ref_batch, loss, argmin);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
