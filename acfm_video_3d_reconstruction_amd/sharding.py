@@ -43,6 +43,42 @@ class SharedGradReducer:
             self._flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
         return self._flat
 
+    def packed(self, n_extra=0, device=None):
+        """The flat exchange buffer and its views: -> (flat, [view per shared parameter], extra view).
+        A step that writes its shared gradients (and loss scalars) straight into these views -- e.g.
+        as the last nodes of a captured hipGraph -- needs no packing or unpacking launches around the
+        collective: `reduce_packed()` is then the ONE launch of the exchange."""
+        ref = next(p for p in self.params)
+        dev = ref.device if device is None else device
+        if self._flat is None or self._flat.device != dev or self._flat.numel() != self.numel + n_extra:
+            self._flat = torch.zeros(self.numel + n_extra, dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for p in self.params:
+            views.append(self._flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        return self._flat, views, self._flat[o:o + n_extra]
+
+    def reduce_packed(self):
+        """All-reduce the buffer of `packed()` in place (sum, or mean with average=True)."""
+        flat = self._flat
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world > 1:
+            staged = flat.is_cuda and dist.get_backend(self.group) == "gloo"   # CPU rehearsal of the multi-rank path
+            buf = flat.cpu() if staged else flat
+            if self.deterministic:
+                parts = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(parts, buf, group=self.group)
+                buf.zero_()
+                for part in parts:
+                    buf.add_(part)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if staged:
+                flat.copy_(buf)
+        if self.average:
+            flat[:self.numel].div_(world)
+        return flat
+
     def reduce(self, extra_scalars=None):
         """All-reduce p.grad of every shared parameter in place.  `extra_scalars`: optional 1-D
         fp32 tensor appended to the same buffer (loss values for logging) and returned summed."""

@@ -129,6 +129,7 @@ def main():
     cams = cams0.clone().requires_grad_(True)
     mean_p = mean_v.clone().requires_grad_(True)
     reducer = SharedGradReducer([mean_p])  # one flat fp32 all-reduce (RCCL) per step
+    _flat, flat_views, flat_extra = reducer.packed(n_extra=1)
 
     params = [delta, cams, mean_p, atlas]
 
@@ -159,12 +160,19 @@ def main():
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
         g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+        if world > 1:
+            # the step writes its shared gradient and loss scalar straight into the exchange buffer (the
+            # last two nodes of the captured graph): the exchange itself is then one RCCL launch
+            flat_views[0].copy_(g_mean)
+            flat_extra.copy_(total.detach().reshape(1))
         return total.detach(), g_delta, g_cams, g_mean, g_atlas
 
     def exchange(total, g_mean):
-        mean_p.grad = g_mean
         if world > 1:  # the one exchange: shared mean-shape gradient + loss scalar
-            reducer.reduce(extra_scalars=total.reshape(1))
+            reducer.reduce_packed()
+            mean_p.grad = flat_views[0]
+        else:
+            mean_p.grad = g_mean
 
     def step(ren=renderer):
         total, g_delta, g_cams, g_mean, g_atlas = compute(ren)

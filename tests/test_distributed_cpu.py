@@ -49,10 +49,17 @@ def _worker(rank, world, port, out):
     P = torch.softmax(lbs, 0)
     loss = _per_frame_loss(mean_v, P, d_loc, cams[s:e]).sum()
     loss.backward()
+    local = (mean_v.grad.clone(), lbs.grad.clone())
     red = SharedGradReducer([mean_v, lbs], deterministic=(rank >= 0))
     tot = red.reduce(extra_scalars=loss.detach().reshape(1))
+    # the packed form (the step writes into the exchange buffer, the exchange is one collective)
+    red2 = SharedGradReducer([mean_v, lbs])
+    flat, views, extra = red2.packed(n_extra=1)
+    views[0].copy_(local[0]); views[1].copy_(local[1]); extra.copy_(loss.detach().reshape(1))
+    red2.reduce_packed()
     if rank == 0:
-        torch.save(dict(mean=mean_v.grad, lbs=lbs.grad, delta=d_loc.grad, loss=tot), out)
+        torch.save(dict(mean=mean_v.grad, lbs=lbs.grad, delta=d_loc.grad, loss=tot,
+                        mean_packed=views[0].clone(), lbs_packed=views[1].clone(), loss_packed=extra.clone()), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,5 +81,8 @@ def test_sharded_grads_match_full_batch(tmp_path):
     np.testing.assert_allclose(got["mean"].numpy(), mean_v.grad.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(got["lbs"].numpy(), lbs.grad.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(got["loss"].item(), loss.item(), rtol=1e-6)
+    np.testing.assert_allclose(got["mean_packed"].numpy(), mean_v.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["lbs_packed"].numpy(), lbs.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["loss_packed"].item(), loss.item(), rtol=1e-6)
     s0, e0 = frame_shard(clips, T, 0, 2)
     np.testing.assert_allclose(got["delta"].numpy(), delta.grad[s0:e0].numpy(), rtol=1e-5, atol=1e-6)
