@@ -6,23 +6,32 @@
 // SURVEY.md App-A; the CPU oracle in oracle/acfm_oracle.c is the bit-level spec).
 //
 // Design:
-//   * k_setup: one workgroup per mesh projects the V vertices into LDS (weak-perspective
-//     camera, y flip, view transform) and writes per-face records + blur-expanded boxes.
+//   * k_setup: four workgroups per mesh project the V vertices into LDS (weak-perspective
+//     camera, y flip, view transform) and write one 64-byte record per face (blur-expanded box,
+//     vertices, depths), the face bitmask of every 32x32 coarse tile and a cost count per 8x8
+//     block; k_order sorts every XCD group's (mesh, block) entries heavy-first (counting sort,
+//     no atomics) and puts the blocks no face box comes near at the end.
 //   * k_raster_fwd / k_sil_bwd share one skeleton: a ONE-WAVE workgroup owns an 8x8 pixel
 //     block (four 4x4 blocks, one per 16-lane group).  Faces are binned against the block with
 //     wave ballots into an LDS candidate list (deterministic, face-ordered, no barriers); the
-//     groups then walk their own sub-lists.  (A 256-thread workgroup per 16x16 tile sharing
-//     one list finished only when its slowest 8x8 block did: 25 % of the wave slots idled.)
+//     groups then walk their own sub-lists.  A launch has entries / div workgroups per group:
+//     workgroup j renders the entries j, j + stride, .. that have work and, in the forward,
+//     first stores the constant outputs of its share of the empty blocks (struct Sched).
 //   * forward, K > 1: every lane keeps its pixel's K nearest (depth|face) keys and blend
-//     factors SORTED in registers (bubble-through insertion on static register indices): no
-//     per-pixel LDS or memory lists (4 waves/SIMD instead of 2), no final sort, the blend
-//     product runs over exactly the kept faces, ids leave as 16-byte stores.
+//     factors SORTED in registers (bubble-through insertion on static register indices, 4-slot
+//     blocks no lane's element can enter are skipped): no per-pixel LDS or memory lists, no final
+//     sort, the blend product runs over exactly the kept faces; the block's candidates are walked
+//     roughly front to back (8 depth classes); ids leave through LDS as 16-byte stores in image
+//     order.  128 VGPRs, 4 waves per SIMD.
+//   * forward, K = 1 (blur 0): only the winner's edge distances are evaluated; 6-7 waves per SIMD.
 //   * backward: the same walk; membership of a face in a pixel's top-K is `key <= kth[pixel]`
-//     (kth saved by the forward), gradients of a candidate are summed across the wave with DPP
-//     row shifts/broadcasts and ONE lane adds them to the tile's LDS vertex accumulator, which
-//     is flushed with one global float atomic per touched coordinate.
-//   * workgroups are dealt so that all tiles of a mesh run on one XCD (its face records stay
+//     (kth saved by the forward), gradients of a candidate are summed over the 16 lanes of its
+//     group with DPP row shifts and ONE lane adds them to the candidate's LDS accumulator, which
+//     is flushed with one global float atomic per touched coordinate.  23 waves per CU.
+//   * workgroups are dealt so that all blocks of a mesh run on one XCD (its face records stay
 //     in that XCD's L2).
+//   * k_tex_bwd_faces: the atlas gradient as a per-face gather over the face's box (no global
+//     atomics); k_tex_bwd: the scatter form (one atomic per covered pixel and channel).
 #include "acfm_common.h"
 
 namespace acfm {

@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-export ACFM_DIST_BACKEND=gloo ACFM_ALL_RANKS_ON_GPU0=1
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 --no-lean > gpurun_out/b2r.json 2> gpurun_out/b2r.err || { tail -30 gpurun_out/b2r.err; exit 1; }
-python -c "
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/t1.log 2>&1 || { tail -40 gpurun_out/t1.log; exit 1; }
+tail -2 gpurun_out/t1.log
+timeout -k 10 300 python bench.py --no-cpu --no-lean > gpurun_out/b8.json 2> gpurun_out/b8.err || { tail -20 gpurun_out/b8.err; exit 1; }
+python - <<'PY'
 import json
-j=json.loads([l for l in open('gpurun_out/b2r.json') if l.startswith('{')][0]); print(j['value'], j['ms_per_step'], j['launch'], j.get('eager_launch'), j.get('launch_note'))"
-unset ACFM_DIST_BACKEND ACFM_ALL_RANKS_ON_GPU0
-timeout -k 10 300 python bench.py --no-cpu --no-lean | python -c "
-import sys, json
-j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j.get('eager_launch'))"
+j = json.load(open("gpurun_out/b8.json"))
+print(j["value"], j["ms_per_step"], j.get("eager_launch"), j.get("launch_note"))
+print({k: round(v["us_per_step"], 1) for k, v in j["kernels"].items()})
+PY
