@@ -73,7 +73,8 @@ __host__ __device__ __forceinline__ int setup_slice_faces(int F) {
 __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
                                                const float* __restrict__ cams, int V, int F, int H,
-                                               float offset_z, int mode, float margin, RasterWs ws) {
+                                               float offset_z, int mode, float margin, RasterWs ws,
+                                               uint8_t* __restrict__ vis) {
   extern __shared__ float s_v[];  // [V][3], then [tiles^2] int counters and this slice's mask words (if they fit)
   __shared__ float s_red[4][4];
   const int n = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
@@ -109,6 +110,12 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     if (slice == 0) {
       float* o = ws.ndc + ((size_t)n * V + v) * 3;
       o[0] = px; o[1] = py; o[2] = pz;
+      // zeroed here instead of by launches of their own: the visible-vertex bytes the raster kernel
+      // marks, and the NDC-gradient scratch the backward accumulates into (k_project_bwd<true> leaves
+      // it zeroed again after reading it)
+      if (vis) vis[(size_t)n * V + v] = 0;
+      ws.grad_ndc[((size_t)n * V + v) * 2] = 0.f;
+      ws.grad_ndc[((size_t)n * V + v) * 2 + 1] = 0.f;
     }
   }
   __syncthreads();
@@ -1341,7 +1348,7 @@ __global__ __launch_bounds__(TPB) void k_project(const float* __restrict__ verts
 template <bool NDC2>
 __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ verts,
                                                      const float* __restrict__ cams,
-                                                     const float* __restrict__ gin, int V,
+                                                     float* gin /* NDC2: cleared after reading */, int V,
                                                      float* __restrict__ grad_verts,
                                                      float* __restrict__ grad_cams) {
   __shared__ float s_red[4][7];
@@ -1356,8 +1363,9 @@ __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ v
     const float X = x[0], Y = x[1], Z = x[2];
     float gx, gy, gz;
     if (NDC2) {
-      const float* g = gin + ((size_t)n * V + v) * 2;
+      float* g = gin + ((size_t)n * V + v) * 2;
       gx = -g[0]; gy = -g[1]; gz = 0.f;
+      g[0] = 0.f; g[1] = 0.f;   // the raster workspace's NDC-gradient scratch is left zeroed for the next backward
     } else {
       const float* g = gin + ((size_t)n * V + v) * 3;
       gx = g[0]; gy = g[1]; gz = g[2];
@@ -1565,7 +1573,7 @@ void prof_end(hipStream_t st) {
 // ------------------------------------------------------------------------------- host side
 static int launch_setup(const float* verts, const int64_t* faces, const float* cams, int N, int V,
                         int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
-                        hipStream_t st) {
+                        hipStream_t st, uint8_t* vis = nullptr) {
   const float margin = sqrtf(blur);
   const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
   const int tt = tiles * tiles;                 // cost counters
@@ -1582,7 +1590,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   if (zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
-                     margin, ws);
+                     margin, ws, vis);
   hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, g_split_mode);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1694,7 +1702,7 @@ int acfm_project_backward(const float* verts, const float* cams, const float* gr
   if (!verts || !cams || !grad_proj || N <= 0 || V <= 0) return ACFM_E_BADARG;
   ProfScope ps(ACFM_PROF_PROJ_BWD, (hipStream_t)stream);
   hipLaunchKernelGGL((k_project_bwd<false>), dim3(N), dim3(TPB), 0, (hipStream_t)stream, verts, cams,
-                     grad_proj, V, grad_verts, grad_cams);
+                     const_cast<float*>(grad_proj), V, grad_verts, grad_cams);  // (read-only in this instantiation)
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -1710,9 +1718,8 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st, vis);
   if (rc) return rc;
-  if (vis && zero_async(vis, (size_t)N * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.dbg = g_dbg;
   out.mask = mask;
@@ -1746,8 +1753,8 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
     int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
     if (rc) return rc;
   }
-  if (zero_async(ws.grad_ndc, sizeof(float) * 2 * (size_t)N * V, st) != ACFM_OK)
-    return ACFM_E_LAUNCH;
+  if (!grad_verts && !grad_cams) return ACFM_OK;   // nothing asked for
+  // ws.grad_ndc is zero here: k_setup cleared it, and every k_project_bwd<true> clears it again after reading
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
@@ -1759,7 +1766,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   if (grad_verts || grad_cams) {
     ProfScope ps(ACFM_PROF_PROJ_BWD, st);
     hipLaunchKernelGGL((k_project_bwd<true>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
-                       (const float*)ws.grad_ndc, V, grad_verts, grad_cams);
+                       ws.grad_ndc, V, grad_verts, grad_cams);
     ACFM_CHECK_LAUNCH();
   }
   return ACFM_OK;
@@ -1771,9 +1778,8 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   const RasterWs ws = carve_ws(wsp, N, V, F, H);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, st);
+  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, st, vis);
   if (rc) return rc;
-  if (vis && zero_async(vis, (size_t)N * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   FwdOut out = {};
   out.dbg = g_dbg;
   out.p2f = pix_to_face;

@@ -383,3 +383,25 @@ def test_hip_graph_capture_and_replay(meshes):
     m3, p3 = [t.detach() for t in step()[:2]]
     np.testing.assert_array_equal(p2.cpu().numpy(), p3.cpu().numpy())
     np.testing.assert_array_equal(m2.cpu().numpy(), m3.cpu().numpy())
+
+
+def test_silhouette_backward_twice_on_one_workspace(meshes):
+    """The raster workspace's NDC-gradient scratch is cleared by the face setup and again by every
+    backward that reads it (no zero-fill launch of its own): a second backward through the same
+    render (retain_graph) gives the same gradients, and so does one with only the cameras asked for."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    verts, f, cams = _setup(meshes, "bird", 3, 71)
+    H = 96
+    tv = torch.tensor(verts, device=d, requires_grad=True)
+    tc = torch.tensor(cams, device=d, requires_grad=True)
+    mask, _ = ops.sil_render(tv, torch.from_numpy(f).to(d), tc, H)
+    w = torch.randn(3, H, H, device=d)
+    loss = (mask * w).sum()
+    g1 = torch.autograd.grad(loss, [tv, tc], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [tv, tc], retain_graph=True)
+    (g3,) = torch.autograd.grad(loss, [tc])
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    assert float((g1[1] - g3).abs().max()) <= 1e-5 * float(g3.abs().max())
+    assert float(g1[0].abs().max()) > 0
