@@ -134,6 +134,73 @@ __global__ void k_deform_grad_mean(const float* __restrict__ g, int N, int V3, f
   atomicAdd(&gmean[i], s);
 }
 
+// grad_delta and grad_mean in ONE launch, without atomics or zero fills (they were two kernels and
+// two zero-fill launches: 21 us of launch latency for a few hundred KB of work):
+//   blocks [0, TK*TJ): one 16x16 tile of grad_delta each; the workgroup's four waves take a quarter of
+//     the inner dimension (V) each and the partial tiles are summed through LDS;
+//   blocks [TK*TJ, ..): grad_mean, one thread per (v, c), four partial sums over the frames in flight.
+constexpr int DM_WAVES = 16;   // waves per workgroup of k_deform_bwd_dm
+__global__ __launch_bounds__(64 * DM_WAVES) void k_deform_bwd_dm(const float* __restrict__ P,
+                                                                const float* __restrict__ g, int N, int V,
+                                                                int Kh, int TK, int TJ,
+                                                                float* __restrict__ gdelta,
+                                                                float* __restrict__ gmean) {
+  __shared__ float s_part[DM_WAVES][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int J = 3 * N;
+  if ((int)blockIdx.x < TK * TJ) {
+    if (!gdelta) return;
+    const int k0 = ((int)blockIdx.x % TK) * 16, j0 = ((int)blockIdx.x / TK) * 16;
+    const int q = ((V + DM_WAVES - 1) / DM_WAVES + 3) / 4 * 4;   // this wave's share of V, multiple of the MFMA's 4
+    const int vb = wv * q, ve = min(vb + q, V);
+    // operands of eight MFMA steps are loaded before the first of them is issued
+    const int i = lane & 15, kk = lane >> 4;
+    const int k = k0 + i, j = j0 + i;
+    const int jn = j / 3, jc = j - 3 * jn;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int v0 = vb; v0 < ve; v0 += 32) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + 4 * u + kk;
+        av[u] = (k < Kh && v < ve) ? P[(size_t)v * Kh + k] : 0.f;
+        bv[u] = (j < J && v < ve) ? g[((size_t)jn * V + v) * 3 + jc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_part[wv][lane * 4 + r] = acc[r];
+    __syncthreads();
+    if (wv != 0) return;
+    const int jo = j0 + (lane & 15);
+    if (jo >= J) return;
+    const int n = jo / 3, c = jo - 3 * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ko = k0 + (lane >> 4) * 4 + r;
+      const int e = lane * 4 + r;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < DM_WAVES; ++w) sum += s_part[w][e];
+      if (ko < Kh) gdelta[((size_t)n * Kh + ko) * 3 + c] = sum;
+    }
+    return;
+  }
+  if (!gmean) return;
+  const int V3 = 3 * V;
+  const int i = ((int)blockIdx.x - TK * TJ) * 64 * DM_WAVES + (int)threadIdx.x;
+  if (i >= V3) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int n = 0;
+  for (; n + 3 < N; n += 4) {
+    s0 += g[(size_t)n * V3 + i]; s1 += g[(size_t)(n + 1) * V3 + i];
+    s2 += g[(size_t)(n + 2) * V3 + i]; s3 += g[(size_t)(n + 3) * V3 + i];
+  }
+  for (; n < N; ++n) s0 += g[(size_t)n * V3 + i];
+  gmean[i] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -156,19 +223,26 @@ int acfm_deform_apply_backward(const float* P, const float* delta, const float* 
   if (!P || !delta || !grad_verts || N <= 0 || V <= 0 || Kh <= 0 || N > 1000000) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_DEFORM_BWD, st);
-  if (grad_delta) {
-    if (zero_async(grad_delta, sizeof(float) * 3 * (size_t)N * Kh, st) != ACFM_OK) return ACFM_E_LAUNCH;
-    hipLaunchKernelGGL(k_deform_grad_delta, dim3((Kh + 15) / 16, (3 * N + 63) / 64, (V + VCHUNK - 1) / VCHUNK),
-                       dim3(256), 0, st, P, grad_verts, N, V, Kh, grad_delta);
+  const int TK = (Kh + 15) / 16, TJ = (3 * N + 15) / 16;
+  const int DMT = 64 * DM_WAVES;
+  if ((grad_delta || grad_mean) && (size_t)TK * TJ + (size_t)(3 * V + DMT - 1) / DMT <= 0x7fffffffull) {
+    hipLaunchKernelGGL(k_deform_bwd_dm, dim3((unsigned)(TK * TJ + (3 * V + DMT - 1) / DMT)), dim3(DMT), 0, st, P,
+                       grad_verts, N, V, Kh, TK, TJ, grad_delta, grad_mean);
+  } else {
+    if (grad_delta) {
+      if (zero_async(grad_delta, sizeof(float) * 3 * (size_t)N * Kh, st) != ACFM_OK) return ACFM_E_LAUNCH;
+      hipLaunchKernelGGL(k_deform_grad_delta, dim3((Kh + 15) / 16, (3 * N + 63) / 64, (V + VCHUNK - 1) / VCHUNK),
+                         dim3(256), 0, st, P, grad_verts, N, V, Kh, grad_delta);
+    }
+    if (grad_mean) {
+      if (zero_async(grad_mean, sizeof(float) * 3 * (size_t)V, st) != ACFM_OK) return ACFM_E_LAUNCH;
+      hipLaunchKernelGGL(k_deform_grad_mean, dim3((3 * V + 255) / 256, (N + MEAN_FRAMES - 1) / MEAN_FRAMES),
+                         dim3(256), 0, st, grad_verts, N, 3 * V, grad_mean);
+    }
   }
   if (grad_P)
     hipLaunchKernelGGL(k_deform_grad_P, dim3((V + 15) / 16, (Kh + 63) / 64), dim3(256), 0, st, grad_verts,
                        delta, N, V, Kh, grad_P);
-  if (grad_mean) {
-    if (zero_async(grad_mean, sizeof(float) * 3 * (size_t)V, st) != ACFM_OK) return ACFM_E_LAUNCH;
-    hipLaunchKernelGGL(k_deform_grad_mean, dim3((3 * V + 255) / 256, (N + MEAN_FRAMES - 1) / MEAN_FRAMES),
-                       dim3(256), 0, st, grad_verts, N, 3 * V, grad_mean);
-  }
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
