@@ -47,6 +47,8 @@ SIGNATURES = {
                                        _i, _f, _vp]),
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_tex_backward_faces": (_i, [_vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_combine_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "acfm_combine_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

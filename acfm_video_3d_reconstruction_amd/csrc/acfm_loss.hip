@@ -347,6 +347,37 @@ __global__ __launch_bounds__(LTPB) void k_of_loss_bwd(const float* __restrict__ 
   atomicAdd(&gk[0], sx * g); atomicAdd(&gk[1], sy * g);
 }
 
+// total = (1/N) sum_n sum_t sum_c w[t][c] T_t[n,c]: the weighted sum of per-mesh loss terms and its mean
+// over the batch (multiframe/main.py:716-746 without the hypothesis weights) as ONE launch each way
+// instead of ~13 elementwise / reduction launches on 64-element vectors forward and as many backward.
+struct CombArgs {
+  const float* t[4];
+  float* g[4];
+  int cols[4];
+  float w[4][4];
+  int nterms;
+};
+__global__ __launch_bounds__(256) void k_combine(CombArgs a, int N, float* __restrict__ total) {
+  __shared__ float s_red[4];
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256)
+    for (int t = 0; t < a.nterms; ++t)
+      for (int c = 0; c < a.cols[t]; ++c)
+        if (a.w[t][c] != 0.f) acc += a.w[t][c] * a.t[t][(size_t)n * a.cols[t] + c];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) total[0] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)N;
+}
+__global__ __launch_bounds__(256) void k_combine_bwd(CombArgs a, int N, const float* __restrict__ go) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float g = go[0] / (float)N;
+  for (int t = 0; t < a.nterms; ++t)
+    if (a.g[t])
+      for (int c = 0; c < a.cols[t]; ++c) a.g[t][(size_t)n * a.cols[t] + c] = a.w[t][c] * g;
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -400,6 +431,44 @@ int acfm_tex_mse_backward(const float* tex, const float* img, const float* mask,
   ProfScope ps(ACFM_PROF_TEX_MSE_BWD, st);
   hipLaunchKernelGGL(k_tex_mse_bwd, dim3((HW + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, N), dim3(LTPB), 0, st,
                      tex, img, mask, grad_out, HW, ref_batch, grad_tex);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+static int fill_comb(CombArgs& a, const void* const* terms, void* const* grads, const int* cols,
+                     const float* weights, int nterms) {
+  if (!cols || !weights || nterms <= 0 || nterms > 4) return ACFM_E_BADARG;
+  a.nterms = nterms;
+  int o = 0;
+  for (int t = 0; t < 4; ++t) {
+    a.t[t] = nullptr; a.g[t] = nullptr; a.cols[t] = 0;
+    for (int c = 0; c < 4; ++c) a.w[t][c] = 0.f;
+    if (t >= nterms) continue;
+    if (cols[t] <= 0 || cols[t] > 4) return ACFM_E_BADARG;
+    a.cols[t] = cols[t];
+    if (terms) { if (!terms[t]) return ACFM_E_BADARG; a.t[t] = (const float*)terms[t]; }
+    if (grads) a.g[t] = (float*)grads[t];
+    for (int c = 0; c < cols[t]; ++c) a.w[t][c] = weights[o++];
+  }
+  return ACFM_OK;
+}
+
+int acfm_combine_losses(const void* const* terms, const int* cols, const float* weights, int nterms, int N,
+                        float* total, void* stream) {
+  CombArgs a;
+  if (!terms || !total || N <= 0 || fill_comb(a, terms, nullptr, cols, weights, nterms) != ACFM_OK)
+    return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, (hipStream_t)stream, a, N, total);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_combine_losses_backward(const float* grad_total, void* const* grads, const int* cols,
+                                 const float* weights, int nterms, int N, void* stream) {
+  CombArgs a;
+  if (!grad_total || !grads || N <= 0 || fill_comb(a, nullptr, grads, cols, weights, nterms) != ACFM_OK)
+    return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_combine_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, N, grad_total);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

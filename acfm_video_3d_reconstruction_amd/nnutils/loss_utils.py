@@ -51,14 +51,25 @@ def edt_loss(mask_rendered, edt, reduce=True):
     return out[:, 3].mean() if reduce else out[:, 3]
 
 
-def fused_silhouette_losses(mask_pred, mask_gt, edt, eps=1e-6):
+def fused_silhouette_losses(mask_pred, mask_gt, edt, eps=1e-6, raw=False):
     """One pass over the rendered mask for all three silhouette terms
-    -> (l1 [N], iou [N], edt [N]); equals l1_loss / iou / edt_loss with reduce=False."""
+    -> (l1 [N], iou [N], edt [N]); equals l1_loss / iou / edt_loss with reduce=False.
+    raw=True: the kernel's [N,4] output (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m) as it is,
+    for combine_losses (no column views, no IoU division: nothing but the one launch)."""
     N = mask_pred.shape[0]
     # mask_gt / edt may be [N/G, ...]: the ground truth of a frame shared by its G hypotheses
     out = ops.mask_losses(mask_pred.reshape(N, -1), mask_gt.reshape(mask_gt.shape[0], -1),
                           edt.reshape(edt.shape[0], -1))
+    if raw:
+        return out
     return out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]
+
+
+def combine_losses(terms, weights):
+    """Weighted total of per-mesh loss terms and its mean over the batch, (1/N) sum_n sum_t w_t * term_t[n]
+    (the elementwise tail of multiframe/main.py:716-765), as one launch forward and one backward.
+    terms: up to 4 tensors [N] or [N,C<=4]; weights: one float per column, term by term."""
+    return ops.combine_losses(terms, weights)
 
 
 _CONJ_SIGN = (1.0, -1.0, -1.0, -1.0)

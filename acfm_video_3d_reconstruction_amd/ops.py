@@ -2,6 +2,7 @@
 
 torch is used here for device memory, streams and autograd bookkeeping only; every op body
 is one or more stream-ordered calls into libacfm_hip.so."""
+import ctypes
 import math
 
 import torch
@@ -586,6 +587,49 @@ class _TexMSE(torch.autograd.Function):
 def tex_mse(tex, img, mask):
     """mean over (3,H,W) of (tex*mask - img*mask)^2 per mesh -> [N]; gradient to tex only."""
     return _TexMSE.apply(tex, img, mask)
+
+
+# ------------------------------------------------------------------------------ loss combination
+class _Combine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        _lib.require_gpu(*terms)
+        ts = [_f32c(t if t.dim() == 2 else t.reshape(t.shape[0], -1)) for t in terms]
+        N = ts[0].shape[0]
+        cols = [int(t.shape[1]) for t in ts]
+        if not 1 <= len(ts) <= 4 or any(t.shape[0] != N for t in ts) or any(c < 1 or c > 4 for c in cols) \
+                or sum(cols) != len(weights):
+            raise ValueError("combine_losses: up to 4 terms [N] or [N,C<=4] with one weight per column")
+        total = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        ctx.args = ((ctypes.c_int * len(cols))(*cols), (ctypes.c_float * len(weights))(*[float(w) for w in weights]),
+                    len(ts), N, [t.shape for t in terms])
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(total.device):
+            _lib.check(_lib.lib().acfm_combine_losses(ptrs, ctx.args[0], ctx.args[1], len(ts), N, _lib.ptr(total),
+                                                      _lib.cur_stream(total.device)), "acfm_combine_losses")
+        return total
+
+    @staticmethod
+    def backward(ctx, go):
+        cols, w, nt, N, shapes = ctx.args
+        g = _f32c(go).reshape(1)
+        need = ctx.needs_input_grad[1:]
+        outs = [torch.empty((N, cols[i]), dtype=torch.float32, device=g.device) if need[i] else None
+                for i in range(nt)]
+        ptrs = (ctypes.c_void_p * nt)(*[(o.data_ptr() if o is not None else None) for o in outs])
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_combine_losses_backward(_lib.ptr(g), ptrs, cols, w, nt, N,
+                                                               _lib.cur_stream(g.device)),
+                       "acfm_combine_losses_backward")
+        return (None,) + tuple(o.reshape(shapes[i]) if o is not None else None for i, o in enumerate(outs))
+
+
+def combine_losses(terms, weights):
+    """(1/N) sum_n sum_t sum_c w[t][c] * terms[t][n, c] -> scalar: the weighted total of per-mesh loss
+    vectors and its batch mean (multiframe/main.py:716-765) as one launch each way.  terms: up to 4
+    tensors [N] or [N, C<=4] (e.g. the [N,4] output of mask_losses as it is); weights: one float per
+    column, flattened term by term."""
+    return _Combine.apply(tuple(float(w) for w in weights), *terms)
 
 
 # ------------------------------------------------------------------------------ boundary loss

@@ -241,6 +241,17 @@ int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, co
                             float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
                             void* stream);
 
+/* ---- loss combination ------------------------------------------------------------------
+ * replaces the elementwise tail of the trainer's total loss (multiframe/main.py:716-746, 749-765:
+ * weight * term + ... then .mean() over the batch): total = (1/N) sum_n sum_t sum_c w[t][c] T_t[n,c]
+ * for up to 4 terms T_t [N, cols[t]] (cols <= 4, dense row-major), one launch each way.
+ * terms / grads / cols / weights are HOST arrays (device pointers inside terms and grads; weights
+ * flattened term by term); a NULL grads[t] skips that term. */
+int acfm_combine_losses(const void* const* terms, const int* cols, const float* weights, int nterms, int N,
+                        float* total, void* stream);
+int acfm_combine_losses_backward(const float* grad_total, void* const* grads, const int* cols,
+                                 const float* weights, int nterms, int N, void* stream);
+
 /* ---- fused silhouette losses ---------------------------------------------------------
  * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False
  * (multiframe/nnutils/loss_utils.py:18-32, 72-77, 245-253) in one pass over the mask:
