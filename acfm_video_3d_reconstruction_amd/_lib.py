@@ -22,6 +22,8 @@ SIGNATURES = {
     "acfm_prof_name": (ctypes.c_char_p, [_i]),
     "acfm_project": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_project_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "acfm_project_xy": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
+    "acfm_project_xy_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "acfm_deform_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_deform_apply_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_correlation_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

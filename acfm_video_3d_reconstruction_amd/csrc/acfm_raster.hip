@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
       float* o = ws.ndc + ((size_t)n * V + v) * 3;
       o[0] = px; o[1] = py; o[2] = pz;
       // zeroed here instead of by launches of their own: the visible-vertex bytes the raster kernel
-      // marks, and the NDC-gradient scratch the backward accumulates into (k_project_bwd<true> leaves
+      // marks, and the NDC-gradient scratch the backward accumulates into (k_project_bwd<1> leaves
       // it zeroed again after reading it)
       if (vis) vis[(size_t)n * V + v] = 0;
       ws.grad_ndc[((size_t)n * V + v) * 2] = 0.f;
@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
 }
 
 // ------------------------------------------------------------------------------- projection
+template <bool XY>   // XY: only (x, y) are stored, [N,V,2] (orthographic_proj / project_points)
 __global__ __launch_bounds__(TPB) void k_project(const float* __restrict__ verts,
                                                  const float* __restrict__ cams, int V, float offset_z,
                                                  float* __restrict__ proj) {
@@ -1333,8 +1334,15 @@ __global__ __launch_bounds__(TPB) void k_project(const float* __restrict__ verts
   const int v = blockIdx.x * TPB + threadIdx.x;
   if (v >= V) return;
   const float* x = verts + ((size_t)n * V + v) * 3;
-  float* o = proj + ((size_t)n * V + v) * 3;
-  project_point(cams + 7 * (size_t)n, x[0], x[1], x[2], offset_z, o[0], o[1], o[2]);
+  float px, py, pz;
+  project_point(cams + 7 * (size_t)n, x[0], x[1], x[2], offset_z, px, py, pz);
+  if (XY) {
+    float* o = proj + ((size_t)n * V + v) * 2;
+    o[0] = px; o[1] = py;
+  } else {
+    float* o = proj + ((size_t)n * V + v) * 3;
+    o[0] = px; o[1] = py; o[2] = pz;
+  }
 }
 
 // Backward of proj = s * rot(q, X) + (tx, ty, offset_z), q not normalised here:
@@ -1343,9 +1351,10 @@ __global__ __launch_bounds__(TPB) void k_project(const float* __restrict__ verts
 //   dL/dq0 = 2 q0 (G.X) + 2 G.(u x X)
 //   dL/du  = -2 (G.X) u + 2 (G.u) X + 2 (u.X) G + 2 q0 (X x G)
 //   dL/dX  = (q0^2 - u.u) G + 2 (G.u) u + 2 q0 (G x u)
-// NDC2 = true: the upstream gradient is grad_ndc [N,V,2] of the rasteriser
-// (x_ndc = -x_p, y_ndc = -y_p, no z gradient on the silhouette path).
-template <bool NDC2>
+// MODE 1 (NDC2): the upstream gradient is grad_ndc [N,V,2] of the rasteriser
+// (x_ndc = -x_p, y_ndc = -y_p, no z gradient on the silhouette path); MODE 2: the gradient of the
+// (x, y) projection [N,V,2] as it is; MODE 0: all three components [N,V,3].
+template <int MODE>
 __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ verts,
                                                      const float* __restrict__ cams,
                                                      float* gin /* NDC2: cleared after reading */, int V,
@@ -1362,10 +1371,13 @@ __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ v
     const float* x = verts + ((size_t)n * V + v) * 3;
     const float X = x[0], Y = x[1], Z = x[2];
     float gx, gy, gz;
-    if (NDC2) {
+    if (MODE == 1) {
       float* g = gin + ((size_t)n * V + v) * 2;
       gx = -g[0]; gy = -g[1]; gz = 0.f;
       g[0] = 0.f; g[1] = 0.f;   // the raster workspace's NDC-gradient scratch is left zeroed for the next backward
+    } else if (MODE == 2) {
+      const float* g = gin + ((size_t)n * V + v) * 2;
+      gx = g[0]; gy = g[1]; gz = 0.f;
     } else {
       const float* g = gin + ((size_t)n * V + v) * 3;
       gx = g[0]; gy = g[1]; gz = g[2];
@@ -1691,7 +1703,7 @@ int acfm_project(const float* verts, const float* cams, int N, int V, float offs
                  void* stream) {
   if (!verts || !cams || !proj || N <= 0 || N > 65535 || V <= 0) return ACFM_E_BADARG;
   ProfScope ps(ACFM_PROF_PROJECT, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_project, dim3((V + TPB - 1) / TPB, N), dim3(TPB), 0, (hipStream_t)stream, verts,
+  hipLaunchKernelGGL((k_project<false>), dim3((V + TPB - 1) / TPB, N), dim3(TPB), 0, (hipStream_t)stream, verts,
                      cams, V, offset_z, proj);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1701,8 +1713,28 @@ int acfm_project_backward(const float* verts, const float* cams, const float* gr
                           float* grad_verts, float* grad_cams, void* stream) {
   if (!verts || !cams || !grad_proj || N <= 0 || V <= 0) return ACFM_E_BADARG;
   ProfScope ps(ACFM_PROF_PROJ_BWD, (hipStream_t)stream);
-  hipLaunchKernelGGL((k_project_bwd<false>), dim3(N), dim3(TPB), 0, (hipStream_t)stream, verts, cams,
+  hipLaunchKernelGGL((k_project_bwd<0>), dim3(N), dim3(TPB), 0, (hipStream_t)stream, verts, cams,
                      const_cast<float*>(grad_proj), V, grad_verts, grad_cams);  // (read-only in this instantiation)
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_project_xy(const float* verts, const float* cams, int N, int V, float offset_z, float* proj_xy,
+                    void* stream) {
+  if (!verts || !cams || !proj_xy || N <= 0 || N > 65535 || V <= 0) return ACFM_E_BADARG;
+  ProfScope ps(ACFM_PROF_PROJECT, (hipStream_t)stream);
+  hipLaunchKernelGGL((k_project<true>), dim3((V + TPB - 1) / TPB, N), dim3(TPB), 0, (hipStream_t)stream, verts,
+                     cams, V, offset_z, proj_xy);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_project_xy_backward(const float* verts, const float* cams, const float* grad_proj_xy, int N, int V,
+                             float* grad_verts, float* grad_cams, void* stream) {
+  if (!verts || !cams || !grad_proj_xy || N <= 0 || V <= 0) return ACFM_E_BADARG;
+  ProfScope ps(ACFM_PROF_PROJ_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL((k_project_bwd<2>), dim3(N), dim3(TPB), 0, (hipStream_t)stream, verts, cams,
+                     const_cast<float*>(grad_proj_xy), V, grad_verts, grad_cams);  // (read-only in this instantiation)
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -1754,7 +1786,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
     if (rc) return rc;
   }
   if (!grad_verts && !grad_cams) return ACFM_OK;   // nothing asked for
-  // ws.grad_ndc is zero here: k_setup cleared it, and every k_project_bwd<true> clears it again after reading
+  // ws.grad_ndc is zero here: k_setup cleared it, and every k_project_bwd<1> clears it again after reading
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
@@ -1765,7 +1797,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   ACFM_CHECK_LAUNCH();
   if (grad_verts || grad_cams) {
     ProfScope ps(ACFM_PROF_PROJ_BWD, st);
-    hipLaunchKernelGGL((k_project_bwd<true>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
+    hipLaunchKernelGGL((k_project_bwd<1>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
                        ws.grad_ndc, V, grad_verts, grad_cams);
     ACFM_CHECK_LAUNCH();
   }

@@ -12,7 +12,7 @@ def orthographic_proj_withz(X, cam, offset_z=0.):
 
 def orthographic_proj(X, cam):
     """geom_utils.py:48-59 -> [B,N,2]."""
-    return ops.project(X, cam, 0.)[:, :, :2]
+    return ops.project_xy(X, cam, 0.)
 
 
 def quat_rotate(X, q):

@@ -42,6 +42,8 @@ class NeuralRenderer(torch.nn.Module):
         return
 
     def project_points(self, verts, cams):  # nmr.py:127-129
+        if self.proj_fn is geom_utils.orthographic_proj_withz:   # the default: (x, y) straight from the kernel
+            return ops.project_xy(verts, cams, 0.)
         return self.proj_fn(verts, cams)[:, :, :2]
 
     def rasterize_of(self, verts, faces, R=None, T=None):
@@ -79,6 +81,8 @@ class OF_NeuralRenderer(torch.nn.Module):
         self.offset_z = 5.
 
     def project_points(self, verts, cams):
+        if self.proj_fn is geom_utils.orthographic_proj_withz:
+            return ops.project_xy(verts, cams, 0.)
         return self.proj_fn(verts, cams)[:, :, :2]
 
     def forward(self, verts, faces):

@@ -98,6 +98,40 @@ class _Project(torch.autograd.Function):
         return gv, gc, None
 
 
+class _ProjectXY(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, cams, offset_z):
+        _lib.require_gpu(verts, cams)
+        v, c = _f32c(verts), _f32c(cams)
+        N, V, _ = v.shape
+        out = torch.empty((N, V, 2), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_project_xy(_lib.ptr(v), _lib.ptr(c), N, V, float(offset_z),
+                                                  _lib.ptr(out), _lib.cur_stream(v.device)), "acfm_project_xy")
+        ctx.save_for_backward(v, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, c = ctx.saved_tensors
+        N, V, _ = v.shape
+        g = _f32c(g)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_project_xy_backward(_lib.ptr(v), _lib.ptr(c), _lib.ptr(g), N, V,
+                                                           _lib.ptr(gv), _lib.ptr(gc),
+                                                           _lib.cur_stream(v.device)),
+                       "acfm_project_xy_backward")
+        return gv, gc, None
+
+
+def project_xy(verts, cams, offset_z=0.0):
+    """The (x, y) part of orthographic_proj_withz, [N,V,2]: bit-identical to project(...)[..., :2],
+    one launch each way (no slice copy forward, no zero-padded [N,V,3] gradient backward)."""
+    return _ProjectXY.apply(verts, cams, offset_z)
+
+
 def project(verts, cams, offset_z=0.0):
     """[N,V,3] x [N,7] -> [N,V,3]; geom_utils.orthographic_proj_withz semantics."""
     return _Project.apply(verts, cams, offset_z)

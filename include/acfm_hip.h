@@ -85,6 +85,13 @@ int acfm_project(const float* verts, const float* cams, int N, int V, float offs
 /* grad_proj [N,V,3] -> grad_verts [N,V,3] (may be NULL), grad_cams [N,7] (may be NULL) */
 int acfm_project_backward(const float* verts, const float* cams, const float* grad_proj, int N,
                           int V, float* grad_verts, float* grad_cams, void* stream);
+/* The (x, y) part only, [N,V,2]: geom_utils.orthographic_proj (geom_utils.py:48-59) and
+ * NeuralRenderer.project_points (nmr.py:127-129) without the [:, :, :2] slice and, backward, without the
+ * zero-padded [N,V,3] gradient the slice's autograd builds. */
+int acfm_project_xy(const float* verts, const float* cams, int N, int V, float offset_z, float* proj_xy,
+                    void* stream);
+int acfm_project_xy_backward(const float* verts, const float* cams, const float* grad_proj_xy, int N, int V,
+                             float* grad_verts, float* grad_cams, void* stream);
 
 /* ---- template deformation --------------------------------------------------------------
  * replaces the per-frame Cholesky solve of multiframe/main.py:586-609 (== predictor.py:260-276,
