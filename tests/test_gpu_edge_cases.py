@@ -154,6 +154,14 @@ def test_full_size_properties_config2(meshes):
     got = np.where(p2f[sel].cpu().numpy() >= 0, got, -1)
     np.testing.assert_array_equal(got, ref_p2f)
     np.testing.assert_allclose(mask[sel].detach().cpu().numpy(), ref_mask, atol=1e-6)
+    # IoU drift against the oracle's masks (BASELINE north_star: < 1e-4), soft and thresholded
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils
+    gt = torch.tensor((np.roll(ref_mask, 5, axis=2) > 0.5).astype(np.float32), device=d)
+    for thr in (None, 0.5):
+        a = mask[sel].detach() if thr is None else (mask[sel].detach() > thr).float()
+        r = torch.tensor(ref_mask if thr is None else (ref_mask > thr).astype(np.float32), device=d)
+        drift = (loss_utils.iou(a, gt) - loss_utils.iou(r, gt)).abs().max().item()
+        assert drift < 1e-4, drift
 
 
 def test_texture_and_flow_on_quadruped_clip(meshes):
