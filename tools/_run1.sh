@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_edge_cases.py -m gpu -x -q -k "full_size" > gpurun_out/t1.log 2>&1 || { tail -40 gpurun_out/t1.log; exit 1; }
-tail -2 gpurun_out/t1.log
+echo "== C5 shard: horse subdiv (2562 v / 5120 f), 16 frames @512"; timeout -k 10 200 python tools/kbench.py --mesh horse --subdiv 1 --frames 16 --img 512 | grep -E "us/iter|sum|coverage"
+echo "== C3: horse 32 @256"; timeout -k 10 100 python tools/kbench.py --mesh horse --frames 32 | grep -E "sum|coverage"
+echo "== C4 shard: cow 32 @256"; timeout -k 10 100 python tools/kbench.py --mesh cow --frames 32 | grep -E "sum|coverage"
+echo "== bird 16 @512"; timeout -k 10 100 python tools/kbench.py --mesh bird --frames 16 --img 512 | grep -E "sum|coverage"
+echo "== bird 128 @256"; timeout -k 10 100 python tools/kbench.py --mesh bird --frames 128 | grep -E "sum|coverage"

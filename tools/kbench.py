@@ -22,12 +22,17 @@ def main():
     p.add_argument("--img", type=int, default=256)
     p.add_argument("--iters", type=int, default=20)
     p.add_argument("--mesh", default="bird")
+    p.add_argument("--subdiv", type=int, default=0, help="SubdivideMeshes passes (1: 642 v / 1280 f -> 2562 v / 5120 f, BASELINE config 5)")
     p.add_argument("--what", default="sil,tex,loss")
     p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
     a = p.parse_args()
     dev = torch.device("cuda:0")
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
     v, f = m[a.mesh + "_v"], m[a.mesh + "_f"]
+    for _ in range(a.subdiv):
+        from oracle import oracle as O      # (test infrastructure: only the mesh subdivision, on the host)
+        v, f = O.subdivide(v, f)
+        f = f.astype(np.int64)
     rng = np.random.default_rng(1000)
     N, H = a.frames, a.img
     verts = torch.tensor(batch_verts(v, N, rng, 0.005), device=dev, requires_grad=True)
