@@ -1,6 +1,7 @@
-"""Randomised parity sweep of the silhouette rasteriser against the CPU oracle (beyond the fixed cases
-of tests/): meshes x image sizes x camera scales x seeds; pix_to_face must match bit for bit, masks
-within 1e-6.  usage: python tools/parity_sweep.py [--cases 40]"""
+"""Randomised parity sweep of the rasteriser against the CPU oracle (beyond the fixed cases of tests/):
+meshes x image sizes x camera scales x seeds; pix_to_face must match bit for bit, masks within 1e-6;
+every third case also checks the silhouette gradients (1e-4 of their scale), the texture render
+(ids bit for bit, images 1e-6) and the atlas gradient.  usage: python tools/parity_sweep.py [--cases 40]"""
 import argparse, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -28,6 +29,25 @@ for case in range(a.cases):
     neq = int((p2f.cpu().numpy() != ref_p2f).sum()); err = float(np.abs(mask.cpu().numpy() - ref_mask).max())
     npx += n * H * H
     ok = neq == 0 and err <= 1e-6
+    if case % 3 == 0 and H <= 128:
+        tv = torch.tensor(verts, device=d, requires_grad=True); tc = torch.tensor(cams, device=d, requires_grad=True)
+        tf = torch.from_numpy(f).to(d)
+        gm = (rng.standard_normal((n, H, H)) / (H * H)).astype(np.float32)
+        m2, _ = ops.sil_render(tv, tf, tc, H, K=K)
+        (m2 * torch.tensor(gm, device=d)).sum().backward()
+        gv, gc, _, _ = O.sil_render_backward(verts, f, cams, H, gm, K=K)
+        ok = ok and np.abs(tv.grad.cpu().numpy() - gv).max() <= 1e-4 * max(np.abs(gv).max(), 1e-20) \
+            and np.abs(tc.grad.cpu().numpy() - gc).max() <= 1e-4 * max(np.abs(gc).max(), 1e-20)
+        R = int(rng.choice([2, 4, 6]))
+        atlas = rng.uniform(0, 1, (n, f.shape[0], R, R, 3)).astype(np.float32)
+        ri, rs, rp, rt = O.tex_render(verts, f, cams, atlas, H)
+        ta = torch.tensor(atlas, device=d, requires_grad=True)
+        imgs, sil, p2 = ops.tex_render(tv.detach(), tf, tc.detach(), ta, H)
+        gi = rng.standard_normal(ri.shape).astype(np.float32)
+        (imgs * torch.tensor(gi, device=d)).sum().backward()
+        ga = O.tex_render_backward_atlas(rt, gi, atlas.shape)
+        ok = ok and bool((p2.cpu().numpy() == rp).all()) and np.abs(imgs.detach().cpu().numpy() - ri).max() <= 1e-6 \
+            and np.abs(ta.grad.cpu().numpy() - ga).max() <= 1e-5 * max(1.0, np.abs(ga).max())
     bad += not ok
     print("case %2d %-5s n=%d H=%3d K=%2d covered %.2f  p2f mismatches %d  max|dmask| %.1e  %s" % (
         case, name, n, H, K, float((ref_p2f[..., 0] >= 0).mean()), neq, err, "ok" if ok else "FAIL"), flush=True)
