@@ -24,16 +24,24 @@ __global__ __launch_bounds__(LTPB) void k_mask_losses(const float* __restrict__ 
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const bool vec = ((HW & 3) == 0);
   if (vec) {
-    for (int i = start + tid * 4; i < end; i += LTPB * 4) {
-      const float4 m = *reinterpret_cast<const float4*>(mask + base + i);
-      float4 g = make_float4(0, 0, 0, 0), e = make_float4(0, 0, 0, 0);
-      if (gt) g = *reinterpret_cast<const float4*>(gt + rbase + i);
-      if (edt) e = *reinterpret_cast<const float4*>(edt + rbase + i);
-      a0 += fabsf(m.x - g.x) + fabsf(m.y - g.y) + fabsf(m.z - g.z) + fabsf(m.w - g.w);
-      a1 += m.x * g.x + m.y * g.y + m.z * g.z + m.w * g.w;
-      a2 += (m.x + g.x - m.x * g.x) + (m.y + g.y - m.y * g.y) + (m.z + g.z - m.z * g.z) +
-            (m.w + g.w - m.w * g.w);
-      a3 += e.x * m.x + e.y * m.y + e.z * m.z + e.w * m.w;
+    // the block's two 16-byte pieces per thread and array are loaded before any of them is used
+    constexpr int U = PIX_PER_BLOCK / (LTPB * 4);
+    float4 m[U], g[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = start + (u * LTPB + tid) * 4;
+      const bool in = i < end;
+      m[u] = in ? *reinterpret_cast<const float4*>(mask + base + i) : make_float4(0, 0, 0, 0);
+      g[u] = (in && gt) ? *reinterpret_cast<const float4*>(gt + rbase + i) : make_float4(0, 0, 0, 0);
+      e[u] = (in && edt) ? *reinterpret_cast<const float4*>(edt + rbase + i) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a0 += fabsf(m[u].x - g[u].x) + fabsf(m[u].y - g[u].y) + fabsf(m[u].z - g[u].z) + fabsf(m[u].w - g[u].w);
+      a1 += m[u].x * g[u].x + m[u].y * g[u].y + m[u].z * g[u].z + m[u].w * g[u].w;
+      a2 += (m[u].x + g[u].x - m[u].x * g[u].x) + (m[u].y + g[u].y - m[u].y * g[u].y) +
+            (m[u].z + g[u].z - m[u].z * g[u].z) + (m[u].w + g[u].w - m[u].w * g[u].w);
+      a3 += e[u].x * m[u].x + e[u].y * m[u].y + e[u].z * m[u].z + e[u].w * m[u].w;
     }
   } else {
     for (int i = start + tid; i < end; i += LTPB) {
