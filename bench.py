@@ -163,7 +163,7 @@ def main():
             total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1])
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
-        g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+        g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, allow_unused=not a.tex)
         if world > 1:
             # the step writes its shared gradient and loss scalar straight into the exchange buffer (the
             # last two nodes of the captured graph): the exchange itself is then one RCCL launch
@@ -250,6 +250,28 @@ def main():
     if not a.no_lean:
         lean = NeuralRenderer(H, pix_to_face_slots=1)
         dt_lean = timed(lean, max(2, a.warmup // 2), a.steps)
+
+    # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
+    # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
+    rv = solver(delta0).detach().requires_grad_(True)
+    rc = cams0.clone().requires_grad_(True)
+    rw = torch.randn(N, H, H, device=dev) / (H * H)
+
+    def render_only():
+        m, _ = renderer(rv, faces, rc)
+        return torch.autograd.grad((m * rw).sum(), [rv, rc])
+    for _ in range(max(2, a.warmup // 2)):
+        render_only()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        render_only()
+    fence()
+    dt_render = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_render], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_render = float(t.item())
 
     # ---- per-kernel durations (hipEvents on the launch stream) over the same K steps
     roof = None
@@ -352,6 +374,11 @@ def main():
             out["hipgraph_replay" if not use_graph else "eager_launch"] = {
                 "value": round(world * N * a.steps / dt_other, 2), "unit": "frames/s",
                 "ms_per_step": round(1e3 * dt_other / a.steps, 4)}
+        out["render_only"] = {
+            "value": round(world * N * a.steps / dt_render, 2), "unit": "frames/s",
+            "ms_per_step": round(1e3 * dt_render / a.steps, 4),
+            "note": "soft-silhouette render K=20 (pix_to_face [N,H,W,20] materialised) + backward to vertices and "
+                    "cameras only; eager launches"}
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",
