@@ -250,6 +250,8 @@ def test_texture_backward_gather_and_scatter_forms(meshes):
         for name, n, G, H, R, share_ws in (("bird", 4, 1, 128, 6, False), ("horse", 4, 2, 100, 4, True),
                                            ("cow", 3, 1, 67, 8, True), ("bird", 2, 1, 256, 2, False)):
             verts, f, cams = _setup(meshes, name, n, 61)
+            if R == 2:                      # a face count that is no multiple of the kernel's four faces per wave
+                f = np.ascontiguousarray(f[:1277])
             rng = np.random.default_rng(62)
             na = n // G
             atlas = rng.uniform(0, 1, (na, f.shape[0], R, R, 3)).astype(np.float32)
