@@ -273,6 +273,62 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_render = float(t.item())
 
+    # ---- SURVEY section 8d's step, every row of it: the headline step + the per-optimiser-step factorisation
+    # of the deformation system with learned handle weights (a8: cot Laplacian, fp64 Cholesky, lbs gradient)
+    # + the mesh priors on the deformed shape (a14 locally_rigid_fn, a15 mesh_laplacian_smoothing 'cot');
+    # reported beside the headline value, never instead of it
+    dt_full = None
+    if a.tex and side is None:
+        from acfm_video_3d_reconstruction_amd.pytorch3d_shim.loss import mesh_laplacian_smoothing
+        from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
+        lbs_p = torch.nn.Parameter(lbs_logits.clone())
+        mean_q = torch.nn.Parameter(mean_v.clone())
+        solver2 = DeformSolver(mean_q, faces[0], lbs_p)
+        mesh_t = Meshes(verts=mean_v[None].repeat(N, 1, 1), faces=faces)
+        params2 = [delta, cams, mean_q, lbs_p, atlas]
+
+        def full_step():
+            solver2.refresh()                                            # lbs / mean shape moved: one factorisation
+            pred_v = solver2(delta)
+            mask, p2f = renderer(pred_v, faces, cams)
+            sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)
+            bdt = L.bds_loss(renderer.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
+            tex, _, _ = renderer(pred_v.detach(), faces, cams, textures=atlas)
+            tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
+            mesh = Meshes(verts=pred_v, faces=faces)
+            prior = 0.1 * L.locally_rigid_fn(mesh, mesh_t) + 0.1 * mesh_laplacian_smoothing(mesh, method="cot")
+            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5]) + prior
+            return torch.autograd.grad(total, params2)
+        full_fn, full_mode = full_step, "eager launches"
+        if not a.eager:
+            try:                                   # the same step as one hipGraph (forward + backward, static shapes)
+                cur = torch.cuda.current_stream(dev)
+                s3 = torch.cuda.Stream(device=dev)
+                s3.wait_stream(cur)
+                with torch.cuda.stream(s3):
+                    for _ in range(3):
+                        full_step()
+                cur.wait_stream(s3)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                    full_outs = full_step()
+                full_fn, full_mode = g2.replay, "one hipGraph replay per step"
+            except Exception as exc:
+                torch.cuda.synchronize()
+                graph_note.append("survey_8d_step: capture failed (%s), eager launch instead" % type(exc).__name__)
+        for _ in range(max(2, a.warmup // 2)):
+            full_fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            full_fn()
+        fence()
+        dt_full = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_full], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_full = float(t.item())
+
     # ---- per-kernel durations (hipEvents on the launch stream) over the same K steps
     roof = None
     kern = {}
@@ -379,6 +435,13 @@ def main():
             "ms_per_step": round(1e3 * dt_render / a.steps, 4),
             "note": "soft-silhouette render K=20 (pix_to_face [N,H,W,20] materialised) + backward to vertices and "
                     "cameras only; eager launches"}
+        if dt_full:
+            out["survey_8d_step"] = {
+                "value": round(world * N * a.steps / dt_full, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * dt_full / a.steps, 4),
+                "note": "headline step + per-step factorisation of the deformation system with learned handle weights "
+                        "(cot Laplacian, fp64 Cholesky, lbs gradient) + locally_rigid_fn + mesh_laplacian_smoothing('cot'); "
+                        + full_mode}
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",
