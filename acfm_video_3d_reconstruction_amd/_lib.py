@@ -57,8 +57,8 @@ SIGNATURES = {
     "acfm_tex_mse_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_cot_laplacian": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "acfm_laplacian_smoothing_state_floats": (_sz, [_i, _i]),
-    "acfm_laplacian_smoothing": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "acfm_laplacian_smoothing_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_laplacian_smoothing": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_laplacian_smoothing_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_edge_rigidity": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "acfm_edge_rigidity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_edt_workspace_bytes": (_sz, [_i, _i, _i]),

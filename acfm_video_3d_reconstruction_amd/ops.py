@@ -741,7 +741,7 @@ def cot_laplacian(verts, faces):
 
 class _LaplacianSmoothing(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts_packed, conn, vweight, method):
+    def forward(ctx, verts_packed, conn, vweight, method, vpm=0, fpm=0):
         _lib.require_gpu(verts_packed, conn, vweight)
         v, w = _f32c(verts_packed), _f32c(vweight)
         c = conn.detach().to(torch.int64).contiguous()
@@ -751,31 +751,32 @@ class _LaplacianSmoothing(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_laplacian_smoothing(_lib.ptr(v), _lib.ptr(c), _lib.ptr(w), P, F,
-                                                           int(method), _lib.ptr(loss), _lib.ptr(state),
-                                                           _lib.cur_stream(v.device)),
+                                                           int(method), int(vpm), int(fpm), _lib.ptr(loss),
+                                                           _lib.ptr(state), _lib.cur_stream(v.device)),
                        "acfm_laplacian_smoothing")
         ctx.save_for_backward(c, state)
-        ctx.cfg = (P, F, int(method))
+        ctx.cfg = (P, F, int(method), int(vpm), int(fpm))
         return loss
 
     @staticmethod
     def backward(ctx, go):
         c, state = ctx.saved_tensors
-        P, F, method = ctx.cfg
+        P, F, method, vpm, fpm = ctx.cfg
         g = _f32c(go).reshape(1)
         gv = torch.empty((P, 3), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().acfm_laplacian_smoothing_backward(_lib.ptr(c), _lib.ptr(state), _lib.ptr(g),
-                                                                    P, F, method, _lib.ptr(gv),
+                                                                    P, F, method, vpm, fpm, _lib.ptr(gv),
                                                                     _lib.cur_stream(g.device)),
                        "acfm_laplacian_smoothing_backward")
-        return gv, None, None, None
+        return gv, None, None, None, None, None
 
 
-def laplacian_smoothing_sum(verts_packed, conn, vweight, method):
+def laplacian_smoothing_sum(verts_packed, conn, vweight, method, verts_per_mesh=0, faces_per_mesh=0):
     """sum_v vweight[v] * |L v|_v on packed meshes; method 0 = cot (conn = faces), 1 = uniform
-    (conn = unique edges)."""
-    return _LaplacianSmoothing.apply(verts_packed, conn, vweight, method)
+    (conn = unique edges).  verts_per_mesh / faces_per_mesh: the packed arrays are equal-sized meshes
+    one after the other (Meshes built from padded [N,V,3] / [N,F,3] tensors): per-mesh LDS kernels."""
+    return _LaplacianSmoothing.apply(verts_packed, conn, vweight, method, verts_per_mesh, faces_per_mesh)
 
 
 class _EdgeRigidity(torch.autograd.Function):

@@ -28,7 +28,10 @@ def mesh_laplacian_smoothing(meshes, method: str = "uniform"):
     if verts.is_cuda and method in ("cot", "uniform"):
         from .. import ops  # fused gfx950 kernels (csrc/acfm_mesh.hip); torch ops below = host tensors
         conn = faces if method == "cot" else meshes.edges_packed()
-        return ops.laplacian_smoothing_sum(verts, conn, weights, 0 if method == "cot" else 1) / N
+        vpm = fpm = 0
+        if method == "cot" and meshes._equal_sized():    # mesh m = verts [m V, (m+1) V), faces [m F, (m+1) F)
+            vpm, fpm = meshes.verts_list()[0].shape[0], meshes.faces_list()[0].shape[0]
+        return ops.laplacian_smoothing_sum(verts, conn, weights, 0 if method == "cot" else 1, vpm, fpm) / N
     if method == "uniform":
         L = meshes.laplacian_packed()
         loss = torch.sparse.mm(L, verts)

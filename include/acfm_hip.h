@@ -308,13 +308,18 @@ int acfm_cot_laplacian(const float* verts, const int64_t* faces, int V, int F, f
  *   method 0 'cot' (conn = faces [F,3]): loss = sum_v vweight[v] * |(W v)_v / rowsum_v - v_v|;
  *   method 1 'uniform' (conn = unique edges [F,2]): W_ij = 1 on edges.
  *   vweight [P] = 1 / (verts of the vertex's mesh); the caller divides the sum by the mesh count.
+ *   verts_per_mesh / faces_per_mesh > 0 (method 0): the packed arrays are equal-sized meshes one after the
+ *   other (mesh m = vertices [m vpm, (m+1) vpm), faces [m fpm, (m+1) fpm)): one workgroup per mesh accumulates
+ *   in LDS, one launch each way; 0 = unknown layout (global atomics).
  *   loss: 1 float (device); state: acfm_laplacian_smoothing_state_floats(P, F) floats kept for
  *   the backward, which takes the upstream gradient as a DEVICE scalar. */
 size_t acfm_laplacian_smoothing_state_floats(int P, int F);
 int acfm_laplacian_smoothing(const float* verts, const int64_t* conn, const float* vweight, int P, int F,
-                             int method, float* loss, float* state, void* stream);
+                             int method, int verts_per_mesh, int faces_per_mesh, float* loss, float* state,
+                             void* stream);
 int acfm_laplacian_smoothing_backward(const int64_t* conn, const float* state, const float* grad_loss, int P,
-                                      int F, int method, float* grad_verts, void* stream);
+                                      int F, int method, int verts_per_mesh, int faces_per_mesh,
+                                      float* grad_verts, void* stream);
 /* acfm_edge_rigidity: loss_utils.locally_rigid_fn (multiframe/nnutils/loss_utils.py:150-164):
  *   loss = sum_e (|v[e0]-v[e1]| - |vt[et0]-vt[et1]|)^2 (the caller divides by the mesh count). */
 int acfm_edge_rigidity(const float* verts, const int64_t* edges, const float* verts_t, const int64_t* edges_t,
