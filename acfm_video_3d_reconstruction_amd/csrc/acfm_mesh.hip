@@ -198,18 +198,17 @@ __global__ __launch_bounds__(LTB) void k_lap_mesh_fwd(const float* __restrict__ 
     }
     const FaceCot c = face_cot(verts, i0 + vb, i1 + vb, i2 + vb);
     wface[3 * f] = c.cota; wface[3 * f + 1] = c.cotb; wface[3 * f + 2] = c.cotc;
-    const long e[3][2] = {{i1, i2}, {i2, i0}, {i0, i1}};
-    const float w[3] = {c.cota, c.cotb, c.cotc};
+    // edge (i1,i2) carries cota, (i2,i0) cotb, (i0,i1) cotc: a vertex receives the two terms of its two
+    // edges of this face in one go (12 LDS atomics per face instead of 24)
+    const long vi[3] = {i0, i1, i2};
+    const float wa[3] = {c.cotc, c.cota, c.cotb};   // weight towards the next vertex of the face
+    const float wb[3] = {c.cotb, c.cotc, c.cota};   // weight towards the previous one
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const long i = e[k][0], j = e[k][1];
+      const long i = vi[k], jn = vi[(k + 1) % 3] + vb, jp = vi[(k + 2) % 3] + vb;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        atomicAdd(&s_wv[3 * i + d], w[k] * verts[3 * (j + vb) + d]);
-        atomicAdd(&s_wv[3 * j + d], w[k] * verts[3 * (i + vb) + d]);
-      }
-      atomicAdd(&s_rs[i], w[k]);
-      atomicAdd(&s_rs[j], w[k]);
+      for (int d = 0; d < 3; ++d) atomicAdd(&s_wv[3 * i + d], wa[k] * verts[3 * jn + d] + wb[k] * verts[3 * jp + d]);
+      atomicAdd(&s_rs[i], wa[k] + wb[k]);
     }
   }
   __syncthreads();
@@ -257,17 +256,16 @@ __global__ __launch_bounds__(LTB) void k_lap_mesh_bwd(const int64_t* __restrict_
     const size_t f = (size_t)m * fpm + fl;
     const long i0 = faces[3 * f] - vb, i1 = faces[3 * f + 1] - vb, i2 = faces[3 * f + 2] - vb;
     if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= vpm || i1 >= vpm || i2 >= vpm) continue;
-    const long e[3][2] = {{i1, i2}, {i2, i0}, {i0, i1}};
+    const long vi[3] = {i0, i1, i2};
+    const float cota = go * wface[3 * f], cotb = go * wface[3 * f + 1], cotc = go * wface[3 * f + 2];
+    const float wa[3] = {cotc, cota, cotb}, wb[3] = {cotb, cotc, cota};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const long i = e[k][0], j = e[k][1];
-      const float w = go * wface[3 * f + k];
-      const float ni = s_nw[i], nj = s_nw[j];
+      const long i = vi[k], jn = vi[(k + 1) % 3], jp = vi[(k + 2) % 3];
+      const float an = wa[k] * s_nw[jn], ap = wb[k] * s_nw[jp];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        atomicAdd(&s_g[3 * j + d], w * ni * glv[3 * (i + vb) + d]);
-        atomicAdd(&s_g[3 * i + d], w * nj * glv[3 * (j + vb) + d]);
-      }
+      for (int d = 0; d < 3; ++d)
+        atomicAdd(&s_g[3 * i + d], an * glv[3 * (jn + vb) + d] + ap * glv[3 * (jp + vb) + d]);
     }
   }
   __syncthreads();
