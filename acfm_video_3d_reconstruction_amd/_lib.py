@@ -60,7 +60,7 @@ SIGNATURES = {
     "acfm_laplacian_smoothing": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_laplacian_smoothing_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_edge_rigidity": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "acfm_edge_rigidity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "acfm_edge_rigidity_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_edt_workspace_bytes": (_sz, [_i, _i, _i]),
     "acfm_edt": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "acfm_boundaries": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -128,8 +128,10 @@ def locally_rigid_fn(meshes, mesh_template):
     N = len(meshes)
     vp = meshes.verts_packed()
     if vp.is_cuda:
+        equal = getattr(meshes, "_equal_sized", None)
+        vpm = meshes.verts_list()[0].shape[0] if (equal is not None and equal()) else 0
         return ops.edge_rigidity_sum(vp, meshes.edges_packed(), mesh_template.verts_packed(),
-                                     mesh_template.edges_packed()) / N
+                                     mesh_template.edges_packed(), vpm) / N
     v0, v1 = _edge_lengths(meshes)
     t0, t1 = _edge_lengths(mesh_template)
     loss = ((v0 - v1).norm(dim=1, p=2) - (t0 - t1).norm(dim=1, p=2)) ** 2

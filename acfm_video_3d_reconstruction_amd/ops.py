@@ -781,7 +781,7 @@ def laplacian_smoothing_sum(verts_packed, conn, vweight, method, verts_per_mesh=
 
 class _EdgeRigidity(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, edges, verts_t, edges_t):
+    def forward(ctx, verts, edges, verts_t, edges_t, vpm=0):
         _lib.require_gpu(verts, edges, verts_t, edges_t)
         v, vt = _f32c(verts), _f32c(verts_t)
         e = edges.detach().to(torch.int64).contiguous()
@@ -794,6 +794,7 @@ class _EdgeRigidity(torch.autograd.Function):
                                                      e.shape[0], _lib.ptr(loss), _lib.cur_stream(v.device)),
                        "acfm_edge_rigidity")
         ctx.save_for_backward(v, e, vt, et)
+        ctx.vpm = int(vpm)
         return loss
 
     @staticmethod
@@ -805,11 +806,13 @@ class _EdgeRigidity(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().acfm_edge_rigidity_backward(
                 _lib.ptr(v), _lib.ptr(e), _lib.ptr(vt), _lib.ptr(et), e.shape[0], v.shape[0], vt.shape[0],
-                _lib.ptr(g), _lib.ptr(gv), _lib.ptr(gvt), _lib.cur_stream(g.device)),
+                ctx.vpm, _lib.ptr(g), _lib.ptr(gv), _lib.ptr(gvt), _lib.cur_stream(g.device)),
                 "acfm_edge_rigidity_backward")
-        return gv, None, gvt, None
+        return gv, None, gvt, None, None
 
 
-def edge_rigidity_sum(verts_packed, edges, verts_t_packed, edges_t):
-    """sum_e (|v[e0]-v[e1]| - |vt[et0]-vt[et1]|)^2 on packed meshes."""
-    return _EdgeRigidity.apply(verts_packed, edges, verts_t_packed, edges_t)
+def edge_rigidity_sum(verts_packed, edges, verts_t_packed, edges_t, verts_per_mesh=0):
+    """sum_e (|v[e0]-v[e1]| - |vt[et0]-vt[et1]|)^2 on packed meshes.  verts_per_mesh > 0: equal-sized
+    meshes and `edges` sorted by its first vertex (Meshes.edges_packed()): the backward accumulates per
+    mesh in LDS instead of with global atomics."""
+    return _EdgeRigidity.apply(verts_packed, edges, verts_t_packed, edges_t, verts_per_mesh)

@@ -325,8 +325,10 @@ int acfm_laplacian_smoothing_backward(const int64_t* conn, const float* state, c
 int acfm_edge_rigidity(const float* verts, const int64_t* edges, const float* verts_t, const int64_t* edges_t,
                        int E, float* loss, void* stream);
 int acfm_edge_rigidity_backward(const float* verts, const int64_t* edges, const float* verts_t,
-                                const int64_t* edges_t, int E, int P, int Pt, const float* grad_loss,
-                                float* grad_verts, float* grad_verts_t, void* stream);
+                                const int64_t* edges_t, int E, int P, int Pt, int verts_per_mesh,
+                                const float* grad_loss, float* grad_verts, float* grad_verts_t, void* stream);
+/* verts_per_mesh > 0: equal-sized meshes and `edges` sorted by its first vertex (Meshes.edges_packed()):
+ * one workgroup per mesh accumulates in LDS (used when only grad_verts is asked for); 0: unknown layout. */
 
 /* ---- on-device input preparation ----------------------------------------
  * replaces the per-batch CPU work of ShapeTrainer.set_input (multiframe/main.py:365-377) and
