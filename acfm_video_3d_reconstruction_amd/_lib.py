@@ -8,7 +8,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libacfm_hip.so")
+# ACFM_LIB: an alternative build of the same C ABI (the diagnostic build libacfm_hip_diag.so, or a kernel
+# variant under test in tools/variants.py); never a fallback -- the path must exist.
+SO_PATH = os.environ.get("ACFM_LIB") or os.path.join(_HERE, "libacfm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -38,15 +40,16 @@ SIGNATURES = {
     "acfm_deform_solve_backward": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp]),
     "acfm_deform_solve_info": (_i, [_vp, _sz, _i, _vp, _vp]),
     "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "acfm_stream_capture_id": (_i, [_vp, _vp]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
-                              _sz, _vp]),
+                              _sz, _vp, _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
-                               _sz, _i, _vp]),
-    "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+                               _sz, _i, _vp, _vp]),
+    "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "acfm_tex_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
-                              _vp, _sz, _i, _f, _i, _vp]),
+                              _vp, _sz, _i, _f, _i, _vp, _vp]),
     "acfm_vertex_color_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
-                                       _i, _f, _vp]),
+                                       _i, _f, _vp, _vp]),
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_tex_backward_faces": (_i, [_vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_combine_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
@@ -127,6 +130,42 @@ def require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError("acfm_video_3d_reconstruction_amd ops run on the GPU only "
                                "(got a %s tensor); there is no CPU fallback" % t.device)
+
+
+class RasterTuning(ctypes.Structure):
+    """AcfmRasterTuning of include/acfm_hip.h (per call; results never depend on it)."""
+    _fields_ = [("split_mode", _i), ("grid_div", _i * 3)]
+
+
+_TUNE = __import__("threading").local()
+
+
+class raster_tuning:
+    """with raster_tuning(split=0, grid_div=(1, 0, 0)): ...   -- every raster op called inside the block
+    (on this thread) passes this tuning to the C ABI; outside any block the library defaults apply.
+    Tests use it to force the split / unsplit kernels and every grid divisor; the library itself keeps
+    no tuning state."""
+
+    def __init__(self, split=-3, grid_div=(0, 0, 0)):
+        self.t = RasterTuning(int(split), (_i * 3)(*[int(d) for d in grid_div]))
+
+    def __enter__(self):
+        self.prev = getattr(_TUNE, "cur", None)
+        _TUNE.cur = self.t
+        return self
+
+    def __exit__(self, *exc):
+        _TUNE.cur = self.prev
+
+
+def tuning():
+    """-> (ctypes pointer or None, the structure to keep alive / to save for the backward)."""
+    t = getattr(_TUNE, "cur", None)
+    return (ctypes.byref(t) if t is not None else None), t
+
+
+def tuning_ptr(t):
+    return ctypes.byref(t) if t is not None else None
 
 
 _CONSTS = {}

@@ -61,10 +61,25 @@ struct RasterWs {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern int g_split_mode;   // split heuristic: < 0 automatic (acfm_raster.hip), 0 never, 1 always
-extern int g_grid_div[3];  // workgroups per XCD group = entries / div: [0] K-nearest forward, [1] nearest-face forward, [2] backward
+// Per-call tuning of the raster launches (AcfmRasterTuning of the C ABI; NULL = these defaults).  There is
+// no process-global knob: every entry point takes its own copy.
+struct Tune {
+  int split = -3;            // split heuristic: < 0 automatic (k_order: split while the longest block > (-split / 2) x mean work per wave slot), 0 never, 1 always
+  int div[3] = {4, 2, 4};    // workgroups per XCD group = entries / div: [0] K-nearest forward, [1] nearest-face forward, [2] backward
+                             // (measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us)
+};
+static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
+  if (!t) return true;
+  if (t->split_mode < -64 || t->split_mode > 1) return false;
+  out.split = t->split_mode;
+  for (int i = 0; i < 3; ++i) {
+    if (t->grid_div[i] < 0 || t->grid_div[i] > 64) return false;
+    if (t->grid_div[i] > 0) out.div[i] = t->grid_div[i];   // 0 = keep the default
+  }
+  return true;
+}
 
-static inline RasterWs carve_ws(void* base, int N, int V, int F, int H) {
+static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_split_mode = -3) {
   RasterWs w;
   {
     // Splitting costs ~25 % more work per split block (four waves bin and merge).  It pays while a

@@ -34,13 +34,13 @@
 //     atomics); k_tex_bwd: the scatter form (one atomic per covered pixel and channel).
 #include "acfm_common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace acfm {
 
-int g_split_mode = -3;   // < 0: automatic, split while longest block > (-mode / 2) x mean work per wave slot; 0 never; 1 always
-// A raster launch has entries / div workgroups per XCD group (see Sched): the flagged-empty blocks
-// -- 70 % of a 256^2 frame of the bird -- cost no workgroup dispatch of their own.
-int g_grid_div[3] = {4, 2, 4};   // measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us
-
+// A raster launch has entries / div workgroups per XCD group (see Sched; div = Tune::div of the call): the
+// flagged-empty blocks -- 70 % of a 256^2 frame of the bird -- cost no workgroup dispatch of their own.
 constexpr int RBLK = 8;       // pixels per block side: one wave64 per block
 constexpr int RT = 64;        // threads per raster workgroup = RBLK*RBLK
 constexpr int RCAP = 128;     // LDS candidate-list capacity of a block (walked early when it could overflow)
@@ -810,10 +810,23 @@ __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, c
   return test_face_dist(xf, yf, A, B, blur, inside, h);
 }
 
-// blend probability sigmoid(-sd/sigma): exact sd/sigma and library expf like the oracle, only
-// the final reciprocal is the 1-ulp v_rcp_f32 (error <= 6e-8 per face, mask tolerance 1e-6)
-__device__ __forceinline__ float sigmoid_neg_fast(float sd, float sigma) {
+// blend probability sigmoid(-sd/sigma) = 1 / (1 + 2^(sd * log2(e)/sigma)) as mul + v_exp_f32 + add +
+// v_rcp_f32 (4 instructions; the IEEE division sd/sigma + library expf + reciprocal were 33, most of them
+// half-rate selects / compares -- tools/ubench/valu_rates.hip).  Error budget against the oracle's exact
+// expf: the product rounds once (|arg| <= 13.3 up to the blur radius: 5.5e-7 relative on 2^arg where
+// p ~ 1e-4, nothing where p ~ 0.5), v_exp_f32 and v_rcp_f32 are 1 ulp each: |dp| <= p (1 - p) 2e-7 + 6e-8 p
+// <= 1e-7 per face; measured on the parity sweep: masks within 4e-7 (bar 1e-6).  Inside faces (sd < 0, far
+// from the edge) underflow to p = 1 exactly like expf does.  Face ids never depend on p.
+#ifndef ACFM_FAST_SIGMOID
+#define ACFM_FAST_SIGMOID 1
+#endif
+__device__ __forceinline__ float sigmoid_scale(float sigma) { return 1.44269504088896341f / sigma; }
+__device__ __forceinline__ float sigmoid_neg_fast(float sd, float sigma, float scale) {
+#if ACFM_FAST_SIGMOID
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sd * scale));
+#else
   return __builtin_amdgcn_rcpf(1.0f + expf(sd / sigma));
+#endif
 }
 
 // (depth, face) key: pz >= 0 so its bit pattern orders like the float; +0.0f folds -0.0 into
@@ -853,6 +866,9 @@ __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& o
 // `lim` (wave-uniform) bounds the number of faces any lane of the wave can hold so far: slots
 // at or beyond it are still empty in every lane, so those compare-exchanges are skipped with
 // scalar branches while every register index stays a compile-time constant.
+#ifndef ACFM_ASM_SLOT
+#define ACFM_ASM_SLOT 1
+#endif
 template <int K, int LO>
 __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], float (&q)[K],
                                               unsigned long long& x, float& xq, int lim) {
@@ -863,11 +879,23 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
   if (__ballot(x < key[HI - 1]) != 0ull) {
 #pragma unroll
     for (int k = LO; k < HI; ++k) {
+#if ACFM_ASM_SLOT
+      // ONE 64-bit compare + six selects.  (With a plain `x < key[k]` the two selects of a pair are
+      // canonicalised into a 64-bit umin / umax, which the backend expands into TWO compares plus register
+      // copies: 9.5 half-rate instructions per slot instead of 7.  The wave-mask compare + inverse ballot
+      // is opaque to that transformation and costs nothing: the mask stays in VCC.)
+      const bool sw = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmpl(x, key[k], 36 /* ICMP_ULT */));
+      const unsigned long long tk = key[k];
+      const float tq = q[k];
+      key[k] = sw ? x : tk; x = sw ? tk : x;
+      q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
+#else
       const bool sw = x < key[k];
       const unsigned long long tk = key[k];
       const float tq = q[k];
       key[k] = sw ? x : tk; x = sw ? tk : x;
       q[k] = sw ? xq : tq;  xq = sw ? tq : xq;
+#endif
     }
   }
   if constexpr (LO + 4 < K) {
@@ -1026,6 +1054,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     // register indices (the displaced farthest entry falls off the end), so there is no LDS or
     // memory list, no final sort and the kept set is exactly the K nearest at every moment.
     unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
+    const float sig_scale = sigmoid_scale(sigma);
     unsigned long long key[K];
     float q[K];
 #pragma unroll
@@ -1056,7 +1085,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 #else
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
 #endif
-        float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma);
+        float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma, sig_scale);
 #ifdef ACFM_DIAG_NO_INSERT
         if (x < key[0]) { key[0] = x; q[0] = xq; }
 #else
@@ -1222,6 +1251,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
   unsigned long long kthkey = KEY_NONE;
+  const float sig_scale = sigmoid_scale(sigma);
   if (t.empty) return;  // the forward wrote mask = 0 here
   if (t.valid) {
     const float m = mask[t.pix];
@@ -1258,7 +1288,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         // inside <=> sd < 0: an inside pixel lies on no edge, so d > 0 and sd = -d < 0
         const bool inside = h.sd < 0.0f;
         // (1-ulp reciprocal in the sigmoid: 1e-7 relative on a gradient checked to 1e-4)
-        const float gs = coef * sigmoid_neg_fast(h.sd, sigma);   // dL / d sd
+        const float gs = coef * sigmoid_neg_fast(h.sd, sigma, sig_scale);   // dL / d sd
         const float gd = inside ? -gs : gs;                      // sd = inside ? -d : d
         // the arg-min edge (01 first, then 02, then 12: SURVEY App-A.4), chosen with selects so that the
         // wave runs ONE distance backward instead of up to three divergent copies of it
@@ -1565,27 +1595,36 @@ __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float*
 }
 
 // ------------------------------------------------------------------------------- profiling
-static bool g_prof_on = false;
+// One ring per process, shared by all devices and threads (a measurement aid, off by default): the
+// flag is atomic, the ring is guarded by a mutex held from prof_begin to prof_end of a launch.
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static hipEvent_t g_ev[ACFM_PROF_RING][2];
 static int g_ev_id[ACFM_PROF_RING];
 static int g_ev_n = 0;
 static bool g_ev_made = false;
+static thread_local bool t_prof_open = false;
 
 void prof_begin(int id, hipStream_t st) {
-  if (!g_prof_on || g_ev_n >= ACFM_PROF_RING) return;
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  g_prof_mu.lock();
+  if (!g_prof_on.load() || g_ev_n >= ACFM_PROF_RING) { g_prof_mu.unlock(); return; }
+  t_prof_open = true;
   g_ev_id[g_ev_n] = id;
   (void)hipEventRecord(g_ev[g_ev_n][0], st);
 }
 void prof_end(hipStream_t st) {
-  if (!g_prof_on || g_ev_n >= ACFM_PROF_RING) return;
+  if (!t_prof_open) return;
   (void)hipEventRecord(g_ev[g_ev_n][1], st);
   g_ev_n++;
+  t_prof_open = false;
+  g_prof_mu.unlock();
 }
 
 // ------------------------------------------------------------------------------- host side
 static int launch_setup(const float* verts, const int64_t* faces, const float* cams, int N, int V,
                         int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
-                        hipStream_t st, uint8_t* vis = nullptr) {
+                        const Tune& tn, hipStream_t st, uint8_t* vis = nullptr) {
   const float margin = sqrtf(blur);
   const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
   const int tt = tiles * tiles;                 // cost counters
@@ -1603,7 +1642,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws, vis);
-  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, g_split_mode);
+  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, tn.split);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -1625,9 +1664,9 @@ static unsigned tile_grid(int N, int H, int div, int split_slots = 0) {
 
 template <int K>
 static int launch_sil_fwd(const RasterWs& ws, int N, int F, int H, float blur, float sigma,
-                          const FwdOut& out, hipStream_t st) {
+                          const FwdOut& out, const Tune& tn, hipStream_t st) {
   ProfScope ps(ACFM_PROF_SIL_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H, g_grid_div[0], ws.split_slots)), dim3(RT), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<K, false, false>), dim3(tile_grid(N, H, tn.div[0], ws.split_slots)), dim3(RT), 0, st, ws, N, F,
                      H, blur, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1639,12 +1678,36 @@ using namespace acfm;
 
 extern "C" {
 
+// Diagnostic builds only (make DIAG=1 -> libacfm_hip_diag.so, used by tools/stamps.py and tools/occ_probe.py):
+// per-workgroup time stamps and the occupancy query.  The shipping library has no such state.
+#ifdef ACFM_DIAG
 static unsigned long long* g_dbg = nullptr;
 int acfm_debug_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)p; return 0; }
+int acfm_debug_occupancy(int which, int dyn_lds) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<20, false, false>, RT, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<1, true, true>, RT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sil_bwd, RT, 0);
+  return e == hipSuccess ? n : -1;
+}
+#else
+static unsigned long long* const g_dbg = nullptr;
+#endif
 int acfm_version(void) { return 1001; }
 const char* acfm_arch(void) { return "gfx950"; }
 
+int acfm_stream_capture_id(void* stream, unsigned long long* id_host) {
+  if (!id_host) return ACFM_E_BADARG;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id) != hipSuccess) return ACFM_E_LAUNCH;
+  *id_host = status == hipStreamCaptureStatusActive ? (id ? id : ~0ull) : 0ull;
+  return ACFM_OK;
+}
+
 int acfm_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (on && !g_ev_made) {
     for (int i = 0; i < ACFM_PROF_RING; ++i)
       if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess)
@@ -1658,6 +1721,7 @@ int acfm_prof_enable(int on) {
 
 int acfm_prof_collect(float* ms_host, int* count_host, int n) {
   if (!ms_host || !count_host || n < ACFM_PROF_NKERNELS) return ACFM_E_BADARG;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < n; ++i) { ms_host[i] = 0.f; count_host[i] = 0; }
   for (int i = 0; i < g_ev_n; ++i) {
     if (hipEventSynchronize(g_ev[i][1]) != hipSuccess) return ACFM_E_LAUNCH;
@@ -1668,21 +1732,6 @@ int acfm_prof_collect(float* ms_host, int* count_host, int n) {
   }
   g_ev_n = 0;
   return ACFM_OK;
-}
-
-// diagnostic (not in the public header): override the block-splitting heuristic (-1 auto, 0 off, 1 on)
-void acfm_debug_set_split(int mode) { acfm::g_split_mode = mode; }
-// diagnostic: workgroups per group = entries / div (which: 0 K-nearest forward, 1 nearest-face forward, 2 backward)
-void acfm_debug_set_grid_div(int which, int div) { if (which >= 0 && which < 3 && div >= 1) acfm::g_grid_div[which] = div; }
-
-// diagnostic (not in the public header): resident workgroups per CU of the raster kernels
-int acfm_debug_occupancy(int which, int dyn_lds) {
-  int n = -1;
-  hipError_t e = hipSuccess;
-  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<20, false, false>, RT, 0);
-  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<1, true, true>, RT, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sil_bwd, RT, 0);
-  return e == hipSuccess ? n : -1;
 }
 
 const char* acfm_prof_name(int id) {
@@ -1742,15 +1791,17 @@ int acfm_project_xy_backward(const float* verts, const float* cams, const float*
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
                      int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
                      float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
-                     size_t ws_bytes, void* stream) {
+                     size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
       (k_out != K && k_out != 1))
     return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st, vis);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, tn, st, vis);
   if (rc) return rc;
   FwdOut out = {};
   out.dbg = g_dbg;
@@ -1761,12 +1812,12 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   out.vis = vis;
   out.V = V;
   switch (K) {
-    case 20: return launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, st);
-    case 10: return launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, st);
-    case 8: return launch_sil_fwd<8>(ws, N, F, H, blur_radius, sigma, out, st);
-    case 4: return launch_sil_fwd<4>(ws, N, F, H, blur_radius, sigma, out, st);
-    case 2: return launch_sil_fwd<2>(ws, N, F, H, blur_radius, sigma, out, st);
-    case 32: return launch_sil_fwd<32>(ws, N, F, H, blur_radius, sigma, out, st);
+    case 20: return launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 10: return launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 8: return launch_sil_fwd<8>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 4: return launch_sil_fwd<4>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 2: return launch_sil_fwd<2>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 32: return launch_sil_fwd<32>(ws, N, F, H, blur_radius, sigma, out, tn, st);
     default: return ACFM_E_BADARG;  // supported K: 2, 4, 8, 10, 20, 32
   }
 }
@@ -1775,14 +1826,16 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
                       const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
                       float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
-                      void* stream) {
+                      const AcfmRasterTuning* tuning, void* stream) {
   if (!verts_world || !faces || !cams || !mask || !kth || !grad_mask || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);   // (same tuning as the forward whose workspace this is)
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (!ws_from_forward) {
-    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, st);
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, tn, st);
     if (rc) return rc;
   }
   if (!grad_verts && !grad_cams) return ACFM_OK;   // nothing asked for
@@ -1790,7 +1843,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, g_grid_div[2], ws.split_slots)), dim3(RT), lds, st, ws, mask,
+    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, tn.div[2], ws.split_slots)), dim3(RT), lds, st, ws, mask,
                        reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
                        blur_radius, sigma);
   }
@@ -1805,12 +1858,15 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
 }
 
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
-                     int64_t* pix_to_face, uint8_t* vis, void* wsp, size_t ws_bytes, void* stream) {
+                     int64_t* pix_to_face, uint8_t* vis, void* wsp, size_t ws_bytes,
+                     const AcfmRasterTuning* tuning, void* stream) {
   if (!verts_proj || !faces || !pix_to_face || !wsp || bad_dims(N, V, F, H)) return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, st, vis);
+  int rc = launch_setup(verts_proj, faces, nullptr, N, V, F, H, 0.f, 1, 0.f, ws, tn, st, vis);
   if (rc) return rc;
   FwdOut out = {};
   out.dbg = g_dbg;
@@ -1818,7 +1874,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   out.vis = vis;
   out.V = V;
   ProfScope ps(ACFM_PROF_HARD_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F,
+  hipLaunchKernelGGL((k_raster_fwd<1, false, false>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F,
                      H, 0.f, 1e-4f, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1827,18 +1883,21 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
                      const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
                      float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
-                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch, void* stream) {
+                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
+                     const AcfmRasterTuning* tuning, void* stream) {
   if (!verts_world || !faces || !cams || !atlas || !imgs || !sil || !pix_to_face || !texel_idx || !wsp)
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
   if (atlas_batch <= 0 || N % atlas_batch != 0) return ACFM_E_BADARG;
   if ((size_t)atlas_batch * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;  // texel_idx is int32
-  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (ws_ready && !(ws_blur >= 0.f)) return ACFM_E_BADARG;
   if (!ws_ready) {
-    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, tn, st);
     if (rc) return rc;
   }
   FwdOut out = {};
@@ -1848,7 +1907,7 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.atlas_n = atlas_batch;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -1857,15 +1916,18 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
 int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
                               const float* verts_rgb, int N, int V, int F, int H, float sigma, float gamma,
                               float offset_z, float* imgs, float* sil, int64_t* pix_to_face, void* wsp,
-                              size_t ws_bytes, int ws_ready, float ws_blur, void* stream) {
+                              size_t ws_bytes, int ws_ready, float ws_blur, const AcfmRasterTuning* tuning,
+                              void* stream) {
   if (!verts_world || !faces || !cams || !verts_rgb || !imgs || !sil || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
-  const RasterWs ws = carve_ws(wsp, N, V, F, H);
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes + sizeof(int32_t) * (size_t)N * H * H > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (ws_ready && !(ws_blur >= 0.f)) return ACFM_E_BADARG;
   if (!ws_ready) {
-    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, st);
+    int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, 0.f, ws, tn, st);
     if (rc) return rc;
   }
   FwdOut out = {};
@@ -1876,7 +1938,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
   out.imgs = imgs; out.sil = sil; out.tidx = (int32_t*)((char*)wsp + ws.bytes); out.R = 1; out.gamma = gamma;
   out.atlas = verts_rgb;  // never dereferenced when vrgb is set
   ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, g_grid_div[1])), dim3(RT), 0, st, ws, N, F, H,
+  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
                      0.f, sigma, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;

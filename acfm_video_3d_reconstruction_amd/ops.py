@@ -53,19 +53,71 @@ def _workspace(N, V, F, H, device):
 # (multiframe/main.py:616-636): when verts / cams / faces are the same storage at the same version,
 # the texture render takes the workspace over instead of setting up again (acfm_tex_forward,
 # ws_ready).  The entry keeps its tensors alive, so an address cannot be recycled under it.
+#
+# What makes a take-over safe -- all of it is part of the key:
+#   * same tensors: storage address, shape and autograd version of verts / cams / faces;
+#   * same HIP stream (the texture render is ordered behind the silhouette render that filled ws);
+#   * same capture: both calls are eager, or both are recorded into the SAME hipGraph capture (id from
+#     hipStreamGetCaptureInfo) -- a workspace never crosses a graph boundary;
+#   * same replay epoch: any hipGraph replay (torch.cuda.CUDAGraph.replay is wrapped below) may have
+#     rewritten static input buffers without touching their version counters, so it ends every sharing.
+# Writes that bypass all of these (`t.data` in-place ops, foreign kernels on raw pointers) are the
+# caller's to announce with invalidate_setups(); share_setup(False) turns the take-over off.
 _SETUP = {}
+_EPOCH = [0]
+_SHARE = [True]
+
+
+def invalidate_setups():
+    """Forget every cached face setup (call after writing to verts / cams / faces behind torch's back)."""
+    _EPOCH[0] += 1
+    _SETUP.clear()
+
+
+def share_setup(on):
+    """Enable / disable the silhouette -> texture workspace take-over (default on).  Returns the old value."""
+    old, _SHARE[0] = _SHARE[0], bool(on)
+    if not on:
+        _SETUP.clear()
+    return old
+
+
+def _wrap_graph_replay():
+    cls = getattr(torch.cuda, "CUDAGraph", None)
+    if cls is None or getattr(cls.replay, "_acfm_wrapped", False):
+        return
+    inner = cls.replay
+
+    def replay(self):
+        _EPOCH[0] += 1          # static buffers may change under unchanged version counters
+        return inner(self)
+    replay._acfm_wrapped = True
+    cls.replay = replay
+
+
+_wrap_graph_replay()
+
+
+def _capture_id(device):
+    """0 when the current stream of `device` is not capturing, else the id of the capture."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    cid = ctypes.c_ulonglong(0)
+    _lib.check(_lib.lib().acfm_stream_capture_id(_lib.cur_stream(device), ctypes.byref(cid)), "acfm_stream_capture_id")
+    return int(cid.value) or -1
 
 
 def _setup_key(v, c, f, H, offset_z):
     return (v.data_ptr(), v._version, tuple(v.shape), c.data_ptr(), c._version, f.data_ptr(), f._version,
-            tuple(f.shape), int(H), float(offset_z))
+            tuple(f.shape), int(H), float(offset_z), torch.cuda.current_stream(v.device).cuda_stream,
+            _capture_id(v.device), _EPOCH[0])
 
 
 def _shared_setup(v, c, f, H, offset_z):
-    """-> (ws, nbytes, blur) of a silhouette render of exactly these inputs, or None."""
-    ent = _SETUP.get(v.device)
+    """-> (ws, nbytes, blur, tuning) of a silhouette render of exactly these inputs, or None."""
+    ent = _SETUP.get(v.device) if _SHARE[0] else None
     if ent is not None and ent[0] == _setup_key(v, c, f, H, offset_z):
-        return ent[1], ent[2], ent[3]
+        return ent[1], ent[2], ent[3], ent[5]
     return None
 
 
@@ -373,15 +425,17 @@ class _SilRender(torch.autograd.Function):
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
+        tp, tune = _lib.tuning()
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
                 float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
-                _lib.ptr(ws), nb, _lib.cur_stream(v.device)), "acfm_sil_forward")
-        _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f))
+                _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)), "acfm_sil_forward")
+        if _SHARE[0]:
+            _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
-        ctx.ws = (ws, nb)  # face records + tile schedule: reused by backward (no second setup)
+        ctx.ws = (ws, nb, tune)  # face records + tile schedule: reused by backward (no second setup)
         ctx.mark_non_differentiable(p2f, vis)
         ctx.set_materialize_grads(False)  # no zero-filled [N,H,H,K] int64 "gradient" for pix_to_face
         return mask, p2f, vis
@@ -397,12 +451,12 @@ class _SilRender(torch.autograd.Function):
         g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
-        ws, nb = ctx.ws
+        ws, nb, tune = ctx.ws
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_backward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
                 V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
-                _lib.cur_stream(v.device)), "acfm_sil_backward")
+                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_backward")
         return gv, None, gc, None, None, None, None, None, None
 
 
@@ -432,7 +486,7 @@ def hard_raster(verts_proj, faces, img_size):
     ws, nb = _workspace(N, V, F, H, v.device)
     with torch.cuda.device(v.device):
         _lib.check(_lib.lib().acfm_hard_raster(_lib.ptr(v), _lib.ptr(f), N, V, F, H, _lib.ptr(p2f),
-                                               _lib.ptr(vis), _lib.ptr(ws), nb,
+                                               _lib.ptr(vis), _lib.ptr(ws), nb, _lib.tuning()[0],
                                                _lib.cur_stream(v.device)), "acfm_hard_raster")
     p2f._acfm_vis = vis
     return p2f
@@ -462,13 +516,17 @@ class _TexRender(torch.autograd.Function):
         p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
         tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         shared = _shared_setup(v, c, f, H, offset_z)
-        ws, nb, ws_blur = shared if shared is not None else (*_workspace(N, V, F, H, v.device), 0.0)
+        if shared is not None:      # the workspace (and the tuning it was carved with) of the silhouette render
+            ws, nb, ws_blur, tune = shared
+        else:
+            ws, nb = _workspace(N, V, F, H, v.device)
+            ws_blur, tune = 0.0, _lib.tuning()[1]
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
                 float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
                 _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
-                _lib.cur_stream(v.device)), "acfm_tex_forward")
+                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R, NA, V)
         ctx.ws = (ws, nb, float(ws_blur))   # face boxes: the gather form of the atlas gradient walks them
@@ -526,7 +584,7 @@ def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gam
         _lib.check(_lib.lib().acfm_vertex_color_forward(
             _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(col), N, V, F, H, float(sigma), float(gamma),
             float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f), _lib.ptr(ws), nb, 0, 0.0,
-            _lib.cur_stream(v.device)), "acfm_vertex_color_forward")
+            _lib.tuning()[0], _lib.cur_stream(v.device)), "acfm_vertex_color_forward")
     return imgs, sil, p2f
 
 

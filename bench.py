@@ -66,13 +66,6 @@ def edt_and_boundaries(gt_mask):
 
 
 def main():
-    if os.environ.get("ACFM_SPLIT") is not None:   # diagnostic: block-splitting heuristic off / on
-        from acfm_video_3d_reconstruction_amd import _lib as _l
-        ctypes.CDLL(_l.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
-    if os.environ.get("ACFM_DIV") is not None:     # diagnostic: raster workgroups per group = entries / div ("fwdK,fwd1,bwd")
-        from acfm_video_3d_reconstruction_amd import _lib as _l
-        for which, d in enumerate(os.environ["ACFM_DIV"].split(",")):
-            ctypes.CDLL(_l.SO_PATH).acfm_debug_set_grid_div(which, int(d))
     a = parse()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))

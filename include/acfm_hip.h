@@ -45,11 +45,17 @@ extern "C" {
 int acfm_version(void);              /* 1000*major + minor */
 const char* acfm_arch(void);         /* "gfx950" */
 
+/* 0 when `stream` is not being captured into a hipGraph, else the (non-zero) id of the capture
+ * (hipStreamGetCaptureInfo).  The Python layer uses it so that a cached face setup is never shared
+ * across a graph boundary (ops._SETUP); no reference counterpart. */
+int acfm_stream_capture_id(void* stream, unsigned long long* id_host);
+
 /* ---- per-kernel timing (measurement aid, off by default) -------------------------------
  * When enabled, every kernel launch inside the entry points is bracketed by hipEvents on
  * the launch stream (ring of ACFM_PROF_RING pairs).  acfm_prof_collect synchronises those
  * events and returns, per kernel id, the summed duration in ms and the launch count since
- * the last collect/enable.  Not for use under hipGraph capture. */
+ * the last collect/enable.  Not for use under hipGraph capture.  The ring is one per process
+ * (all devices and threads share it, guarded by a mutex): a diagnostic, not a product feature. */
 #define ACFM_PROF_SETUP 0
 #define ACFM_PROF_SIL_FWD 1
 #define ACFM_PROF_SIL_BWD 2
@@ -171,6 +177,19 @@ int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_hos
  * (face records, NDC verts, per-mesh boxes, tile schedule, gradient scratch). */
 size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
 
+/* Per-call launch tuning of the raster entry points (pure speed: results never depend on it).
+ * NULL = the defaults.  There is no process-global tuning state in the library.
+ *   split_mode: the heaviest 8x8 blocks of a small launch are rendered by four workgroups each;
+ *               < 0 automatic (decided on the device from the cost histogram; default -3),
+ *               0 never, 1 always (for every launch size);
+ *   grid_div:   workgroups per XCD group = entries / div for [0] the K-nearest forward, [1] the
+ *               nearest-face (K = 1) forward, [2] the silhouette backward; 0 = default (4, 2, 4).
+ * A backward call must pass the tuning of the forward whose workspace it takes over. */
+typedef struct AcfmRasterTuning {
+  int split_mode;
+  int grid_div[3];
+} AcfmRasterTuning;
+
 /* ---- soft silhouette ---------------------------------------------------------------
  * replaces NeuralRenderer.forward, mask branch (multiframe/nnutils/nmr.py:143-172):
  * proj_fn -> y flip -> view (R=diag(-1,1,1), T=(0,0,2.732)) -> PyTorch3D
@@ -188,7 +207,7 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N,
                      int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
                      float offset_z, float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis,
-                     void* ws, size_t ws_bytes, void* stream);
+                     void* ws, size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
@@ -199,7 +218,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
                       const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z,
                       float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
-                      int ws_from_forward, void* stream);
+                      int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
 
 /* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
  * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are
@@ -207,7 +226,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
  * -> pix_to_face [N,H,H,1] i64 */
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
                      int64_t* pix_to_face, uint8_t* vis /* optional [N,V], as above */, void* ws,
-                     size_t ws_bytes, void* stream);
+                     size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream);
 
 /* ---- atlas-textured render -----------------------------------------------------------
  * replaces NeuralRenderer.forward, texture branch with atlas=True
@@ -228,14 +247,15 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
                      const float* atlas, int N, int V, int F, int H, int R, float sigma,
                      float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
                      int32_t* texel_idx, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
-                     int atlas_batch, void* stream);
+                     int atlas_batch, const AcfmRasterTuning* tuning, void* stream);
 /* NeuralRenderer.forward with atlas=False (multiframe/nnutils/nmr.py:177-179, used by
  * utils/bird_vis.py for visualisation): Textures(verts_rgb) = barycentric interpolation of
  * per-vertex colours verts_rgb [N,V,3]; forward only.  Workspace: raster workspace + 4*N*H*H. */
 int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
                               const float* verts_rgb, int N, int V, int F, int H, float sigma,
                               float gamma, float offset_z, float* imgs, float* sil,
-                              int64_t* pix_to_face, void* ws, size_t ws_bytes, int ws_ready, float ws_blur, void* stream);
+                              int64_t* pix_to_face, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
+                              const AcfmRasterTuning* tuning, void* stream);
 /* grad_imgs [N,3,H,H] -> grad_atlas [N,F,R,R,3] (zeroed here, then scatter-added).
  * Integer texel indexing sends no gradient to geometry. */
 int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, int F, int H, int R, int atlas_batch,

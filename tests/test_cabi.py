@@ -32,6 +32,18 @@ def test_library_exports_every_declared_symbol():
     assert h.acfm_raster_workspace_bytes(0, 642, 1280, 256) == 0
 
 
+def test_library_exports_nothing_undeclared():
+    """No hidden knobs: every acfm_* symbol the shipping library exports is declared in the public
+    header (the acfm_debug_* diagnostics exist only in the DIAG build, tuning is per call)."""
+    import subprocess
+    from acfm_video_3d_reconstruction_amd import _lib
+    _lib.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.SO_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("acfm_")}
+    assert exported == set(_declared_symbols()), sorted(exported ^ set(_declared_symbols()))
+    assert not any("debug" in s for s in exported)
+
+
 def test_no_cpu_fallback():
     from acfm_video_3d_reconstruction_amd import ops
     from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer

@@ -200,23 +200,18 @@ def test_split_and_unsplit_heavy_blocks_agree(meshes):
     """The heaviest blocks of a small launch are rendered by four workgroups each (candidate-parallel,
     merged K-nearest lists); forced on and forced off both reproduce the oracle: pix_to_face bit for
     bit, mask and gradients within tolerance."""
-    import ctypes
     from acfm_video_3d_reconstruction_amd import _lib
     from acfm_video_3d_reconstruction_amd.synthetic import batch_verts, make_cams
-    raw = ctypes.CDLL(_lib.SO_PATH)
     rng = np.random.default_rng(77)
     v, f = meshes["bird_v"], meshes["bird_f"]
     n, H = 3, 96
     verts = batch_verts(v, n, rng, 0.005)
     cams = make_cams(n, rng, extent=float(np.abs(v).max()))
     cams[:, 0] *= 0.35                                     # a small bird: > 80 face boxes on its blocks
-    try:
-        for mode in (1, 0):
-            raw.acfm_debug_set_split(mode)
+    for mode in (1, 0):
+        with _lib.raster_tuning(split=mode):       # per-call tuning of the C ABI (AcfmRasterTuning): no global state
             _check_sil(verts, f, cams, H, seed=mode)
             _check_sil(verts, f, cams, H, K=4, seed=mode)
-    finally:
-        raw.acfm_debug_set_split(-3)
 
 
 def test_workgroups_render_several_blocks_and_fill_the_empty_ones(meshes):
@@ -225,37 +220,30 @@ def test_workgroups_render_several_blocks_and_fill_the_empty_ones(meshes):
     work.  Close-up frames (most blocks have work: several per workgroup), a far-away mesh (nearly all
     blocks empty: several fills per workgroup), batches of 8 (eight groups) and of 3 (one group), every
     divisor from 1 to 7: pix_to_face bit for bit, mask, gradients, texture render and hard raster."""
-    import ctypes
     from acfm_video_3d_reconstruction_amd import _lib, ops
-    raw = ctypes.CDLL(_lib.SO_PATH)
     d = _dev()
     v, f = meshes["bird_v"], meshes["bird_f"]
     ext = float(np.abs(v).max())
-    try:
-        for n, H, zoom, divs in ((8, 64, 2.2, (1, 3, 7)), (3, 72, 1.8, (2, 5)), (8, 64, 0.25, (4, 7))):
-            rng = np.random.default_rng(90 + n)
-            verts = batch_verts(v, n, rng, 0.005)
-            cams = make_cams(n, rng, extent=ext)
-            cams[:, 0] *= zoom
-            atlas = rng.uniform(0, 1, (n, f.shape[0], 2, 2, 3)).astype(np.float32)
-            ri, rs, rp2, _ = O.tex_render(verts, f, cams, atlas, H)
-            proj = O.project(verts, cams)
-            rof = O.of_raster(proj, f, H)
-            for dv in divs:
-                for which in range(3):
-                    raw.acfm_debug_set_grid_div(which, dv)
-                p = _check_sil(verts, f, cams, H, seed=dv)
-                if zoom > 1:
-                    assert (p[..., 0] >= 0).mean() > 0.4       # about half of the blocks have work: several per workgroup
-                tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
-                tf = torch.from_numpy(f).to(d)
-                imgs, sil, p2 = ops.tex_render(tv, tf, tc, torch.tensor(atlas, device=d), H)
-                np.testing.assert_array_equal(p2.cpu().numpy(), rp2)
-                np.testing.assert_allclose(imgs.cpu().numpy(), ri, atol=1e-6)
-                np.testing.assert_allclose(sil.cpu().numpy(), rs, atol=1e-6)
-                po = ops.hard_raster(torch.tensor(proj, device=d), tf, H)
-                po = po[0] if isinstance(po, (tuple, list)) else po
-                np.testing.assert_array_equal(po.cpu().numpy(), rof)
-    finally:
-        for which, dv in enumerate((4, 2, 4)):
-            raw.acfm_debug_set_grid_div(which, dv)
+    for n, H, zoom, divs in ((8, 64, 2.2, (1, 3, 7)), (3, 72, 1.8, (2, 5)), (8, 64, 0.25, (4, 7))):
+        rng = np.random.default_rng(90 + n)
+        verts = batch_verts(v, n, rng, 0.005)
+        cams = make_cams(n, rng, extent=ext)
+        cams[:, 0] *= zoom
+        atlas = rng.uniform(0, 1, (n, f.shape[0], 2, 2, 3)).astype(np.float32)
+        ri, rs, rp2, _ = O.tex_render(verts, f, cams, atlas, H)
+        proj = O.project(verts, cams)
+        rof = O.of_raster(proj, f, H)
+        for dv in divs:
+          with _lib.raster_tuning(grid_div=(dv, dv, dv)):
+            p = _check_sil(verts, f, cams, H, seed=dv)
+            if zoom > 1:
+                assert (p[..., 0] >= 0).mean() > 0.4       # about half of the blocks have work: several per workgroup
+            tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+            tf = torch.from_numpy(f).to(d)
+            imgs, sil, p2 = ops.tex_render(tv, tf, tc, torch.tensor(atlas, device=d), H)
+            np.testing.assert_array_equal(p2.cpu().numpy(), rp2)
+            np.testing.assert_allclose(imgs.cpu().numpy(), ri, atol=1e-6)
+            np.testing.assert_allclose(sil.cpu().numpy(), rs, atol=1e-6)
+            po = ops.hard_raster(torch.tensor(proj, device=d), tf, H)
+            po = po[0] if isinstance(po, (tuple, list)) else po
+            np.testing.assert_array_equal(po.cpu().numpy(), rof)

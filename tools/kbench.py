@@ -25,6 +25,8 @@ def main():
     p.add_argument("--subdiv", type=int, default=0, help="SubdivideMeshes passes (1: 642 v / 1280 f -> 2562 v / 5120 f, BASELINE config 5)")
     p.add_argument("--what", default="sil,tex,loss")
     p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
+    p.add_argument("--split", type=int, default=-3, help="block splitting: < 0 automatic, 0 never, 1 always")
+    p.add_argument("--div", default="0,0,0", help="workgroups per group = entries / div: fwdK,fwd1,bwd (0 = default)")
     a = p.parse_args()
     dev = torch.device("cuda:0")
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
@@ -43,11 +45,9 @@ def main():
     atlas = torch.rand(N, f.shape[0], 6, 6, 3, device=dev, requires_grad=True)
     bds = torch.cat([torch.rand(N, 800, 2, device=dev) * 2 - 1, torch.ones(N, 800, 1, device=dev)], -1)
     lib = _lib.lib()
-    if os.environ.get("ACFM_SPLIT") is not None:
-        ctypes.CDLL(_lib.SO_PATH).acfm_debug_set_split(int(os.environ["ACFM_SPLIT"]))
-    if os.environ.get("ACFM_DIV") is not None:   # workgroups per group = entries / div: "fwdK,fwd1,bwd"
-        for which, d in enumerate(os.environ["ACFM_DIV"].split(",")):
-            ctypes.CDLL(_lib.SO_PATH).acfm_debug_set_grid_div(which, int(d))
+    # --split / --div: per-call tuning of the raster entry points (AcfmRasterTuning), for experiments
+    tune = _lib.raster_tuning(split=a.split, grid_div=tuple(int(x) for x in a.div.split(",")))
+    tune.__enter__()
 
     def run():
         if "sil" in a.what:

@@ -3,6 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 from acfm_video_3d_reconstruction_amd import _lib
 torch.zeros(1, device="cuda")
+assert _lib.SO_PATH.endswith("_diag.so"), "run with ACFM_LIB=<path to libacfm_hip_diag.so> (make DIAG=1)"
 raw = ctypes.CDLL(_lib.SO_PATH)
 for w, name in ((0, "fwd K=20"), (1, "fwd K=1 tex"), (2, "bwd")):
     print(name, "workgroups (waves) per CU:", raw.acfm_debug_occupancy(w, 2 * 642 * 4))
