@@ -30,6 +30,16 @@ DEFAULTS = dict(num_frames=2, num_guesses=8, num_lbs=15, kp_loss_wt=0., of_loss_
                 optimize_deform_lr=100., drop_hypothesis=False, texture=False, cam_loss_wt=2., deform_loss_wt=2.)
 
 
+def texture_cycle_loss(textures, num_frames):
+    """The texture temporal-consistency term of ShapeTrainer.forward, literally (multiframe/main.py:705-711):
+    the per-frame atlases [B*T,F,R,R,3] are regrouped as [B,F,R,R,T,3] and then RESHAPED to [-1,R,R] -- the
+    reference's own regrouping of the trailing (R, T, 3) block, reproduced as written, not "fixed" -- and the
+    loss is the mean L2 norm (over the last axis) of the differences of neighbours along axis 1."""
+    t_c = textures.reshape(-1, num_frames, *textures.shape[1:]).permute(0, 2, 3, 4, 1, 5)
+    t_c = t_c.reshape(-1, t_c.shape[2], t_c.shape[3])
+    return torch.norm(t_c[:, :-1] - t_c[:, 1:], p=2, dim=-1).mean()
+
+
 def _y_rotation_quats(num_guesses):
     """mesh_net.py:424-434: hypothesis g starts as a rotation of 360*g/(G-1) degrees about +y."""
     ang = torch.linspace(0, 360, num_guesses) * math.pi / 180.0
@@ -178,8 +188,11 @@ class MultiframeStep(nn.Module):
         terms = {}
         mask_pred, mask_loss, sil_cons = self._silhouette_terms(pred_v, faces, cam, batch, G)
         total = o.mask_loss_wt * mask_loss.reshape(G, N)
-        total = total + o.of_loss_wt * self._flow_term(pred_v, cam, batch, G)
+        of_term = self._flow_term(pred_v, cam, batch, G)
+        total = total + o.of_loss_wt * of_term
         total = total + o.boundaries_reg_wt * sil_cons.reshape(G, N)
+        terms.update(cam_pred=cam.detach(), pred_v=pred_v1.detach(), mask_loss=mask_loss.reshape(G, N).detach(),
+                     sil_cons_per_hyp=sil_cons.reshape(G, N).detach(), of_loss=of_term.detach())
         if o.kp_loss_wt > 0 and self.vert2kp is not None:
             kp_v = torch.matmul(torch.softmax(self.vert2kp, dim=1), pred_v)
             kp = loss_utils.kp_l2_loss(self.renderer.project_points(kp_v, cam), batch["kps"].repeat(G, 1, 1),
@@ -198,8 +211,11 @@ class MultiframeStep(nn.Module):
                          + loss_utils.masked_texture_mse(tex_pred_f, imgs_f, masks_f))
             total = total + o.tex_loss_wt * mse.reshape(G, N)
             terms["tex_mse"] = mse.mean().detach()
+            terms["tex_mse_per_hyp"] = mse.reshape(G, N).detach()
+            cycle = texture_cycle_loss(textures, T)              # main.py:705-711, added at :749
         # hypothesis weighting (main.py:735-746)
         weighted, probs, cam_loss = harness.hypothesis_weighting(total)
+        terms.update(total_per_hyp=total.detach(), weighted=weighted.detach())
         if selected is not None:                   # probabilities go back to the embeddings they came from (:737-742)
             with torch.no_grad():
                 fi = batch["frames_idx"]
@@ -214,6 +230,9 @@ class MultiframeStep(nn.Module):
         rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
         handle = loss_utils.deform_l2reg(delta_v_res)
         loss = weighted + o.rigid_wt * rigid + o.triangle_reg_wt * triangle + o.handle_deform_reg_wt * handle
+        if textures is not None and imgs is not None:
+            loss = loss + o.deform_reg_wt * cycle                # main.py:749 (deform_reg_wt weighs the texture cycle term)
+            terms["cycle"] = cycle.detach()
         if predicted_camera is not None:           # main.py:753-762: camera head vs the most probable hypothesis
             best = probs.reshape(G, N).argmax(dim=0)
             cam_sel = cam.reshape(G, N, 7)[best, torch.arange(N, device=cam.device)]

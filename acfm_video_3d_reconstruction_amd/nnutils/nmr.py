@@ -48,7 +48,16 @@ class NeuralRenderer(torch.nn.Module):
 
     def rasterize_of(self, verts, faces, R=None, T=None):
         """nmr.py:131-141: hard K=1 raster of already-projected verts.  The reference passes
-        the look_at R/T of OF_NeuralRenderer; only that fixed view is supported."""
+        the look_at R/T of OF_NeuralRenderer (R = diag(-1, 1, 1), T = (0, 0, 2.732), nmr.py:224-231);
+        only that fixed view is built into the kernels: any other R / T raises instead of being ignored."""
+        if R is not None:
+            Rm = torch.as_tensor(R, dtype=torch.float32).reshape(-1, 3, 3).cpu()
+            if not torch.allclose(Rm, torch.diag(torch.tensor([-1., 1., 1.]))[None].expand_as(Rm), atol=1e-6):
+                raise ValueError("rasterize_of: only the reference's view R = diag(-1, 1, 1) is supported")
+        if T is not None:
+            Tm = torch.as_tensor(T, dtype=torch.float32).reshape(-1, 3).cpu()
+            if not torch.allclose(Tm, torch.tensor([0., 0., 2.732])[None].expand_as(Tm), atol=1e-6):
+                raise ValueError("rasterize_of: only the reference's view T = (0, 0, 2.732) is supported")
         return ops.hard_raster(verts, faces, self.img_size)
 
     def forward(self, vertices, faces, cams, textures=None, atlas=True):

@@ -107,10 +107,14 @@ class Meshes:
             ck = None
             if self._faces_padded is not None and self._equal_sized():
                 fp_ = self._faces_padded
-                ck = (fp_.data_ptr(), tuple(fp_.shape), fp_._version, str(fp_.device),
-                      self._verts_list[0].shape[0])
-            if ck is not None and ck in _EDGE_CACHE:
-                self._cache["edges_packed"] = _EDGE_CACHE[ck]
+                ck = (fp_.data_ptr(), tuple(fp_.shape), tuple(fp_.stride()), fp_._version, str(fp_.device),
+                      str(fp_.dtype), self._verts_list[0].shape[0])
+            hit = _EDGE_CACHE.get(ck) if ck is not None else None
+            if hit is not None:
+                # the entry holds its source tensor: while the key is in the table the storage stays alive, so
+                # the address cannot be handed to another [N,F,3] tensor with a different topology, and any
+                # tensor that matches (address, strides, shape, version) is a view of the same values
+                self._cache["edges_packed"] = hit[1]
             else:
                 f = self.faces_packed()
                 e = torch.cat([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)
@@ -121,7 +125,7 @@ class Meshes:
                 if ck is not None:
                     if len(_EDGE_CACHE) > 16:
                         _EDGE_CACHE.clear()
-                    _EDGE_CACHE[ck] = self._cache["edges_packed"]
+                    _EDGE_CACHE[ck] = (fp_, self._cache["edges_packed"])
         return self._cache["edges_packed"]
 
     def laplacian_packed(self):

@@ -11,6 +11,33 @@ import torch
 from .nnutils import loss_utils
 
 
+def refine_total(renderer, solver, delta, cam, faces, masks, edts_barrier, boundaries, mask_loss_wt=1.0,
+                 boundaries_reg_wt=1.0, edt_reg_wt=0.1, bdt_reg_wt=0.1, of_loss_wt=0.0, optical_flows=None,
+                 of_renderer=None, num_frames=2):
+    """The loss of one refinement iteration (predictor.py:310-345) for handle offsets `delta` [N,K_h,3] and
+    cameras `cam` [N,7]: -> (total, pred_v).  refine_clip() differentiates exactly this."""
+    pred_v = solver(delta)                                                    # predictor.py:310-315
+    mask_pred, pix_to_face = renderer(pred_v, faces, cam)                     # :317
+    l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
+    pred_proj = renderer.project_points(pred_v, cam)                          # :319
+    bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
+    # mask_loss = l1.mean() (:318), edt_loss = edt.mean() (:320); the reference pairs bdt_reg_wt with
+    # the EDT term and edt_reg_wt with the boundary term (:322); total as at :343-344, with the two
+    # per-frame means folded into one
+    per_frame = mask_loss_wt * l1 + (boundaries_reg_wt * bdt_reg_wt) * edt
+    total = per_frame.mean() + (boundaries_reg_wt * edt_reg_wt) * bdt_loss
+    if of_loss_wt > 0 and optical_flows is not None:
+        b = optical_flows.shape[0]
+        masks_of = masks.reshape(b, num_frames, masks.shape[1], masks.shape[2])
+        pred_v_of = pred_v.reshape(b, num_frames, pred_v.shape[1], pred_v.shape[2])
+        faces_of = faces.reshape(b, num_frames, faces.shape[1], 3)
+        flows_f = torch.flip(optical_flows, dims=[1]) * masks_of[..., None]
+        of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v_of, faces_of, cam, flows_f,
+                                                           of_renderer, pix_to_face)   # :334-339
+        total = total + of_loss_wt * of_loss
+    return total, pred_v
+
+
 def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
                 num_optim_iter=20, optimize_camera=False, mask_loss_wt=1.0, boundaries_reg_wt=1.0,
                 edt_reg_wt=0.1, bdt_reg_wt=0.1, of_loss_wt=0.0, optical_flows=None, of_renderer=None,
@@ -45,25 +72,9 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
                 cam = ops.camera_normalize(cam_raw)
             else:
                 cam = torch.cat([cam_raw[:, :3], torch.nn.functional.normalize(cam_raw[:, 3:], dim=-1)], dim=1)
-        pred_v = solver(delta)                                                    # predictor.py:310-315
-        mask_pred, pix_to_face = renderer(pred_v, faces, cam)                     # :317
-        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
-        pred_proj = renderer.project_points(pred_v, cam)                          # :319
-        bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
-        # mask_loss = l1.mean() (:318), edt_loss = edt.mean() (:320); the reference pairs bdt_reg_wt with
-        # the EDT term and edt_reg_wt with the boundary term (:322); total as at :343-344, with the two
-        # per-frame means folded into one
-        per_frame = mask_loss_wt * l1 + (boundaries_reg_wt * bdt_reg_wt) * edt
-        total = per_frame.mean() + (boundaries_reg_wt * edt_reg_wt) * bdt_loss
-        if of_loss_wt > 0 and optical_flows is not None:
-            b = optical_flows.shape[0]
-            masks_of = masks.reshape(b, num_frames, masks.shape[1], masks.shape[2])
-            pred_v_of = pred_v.reshape(b, num_frames, pred_v.shape[1], pred_v.shape[2])
-            faces_of = faces.reshape(b, num_frames, faces.shape[1], 3)
-            flows_f = torch.flip(optical_flows, dims=[1]) * masks_of[..., None]
-            of_loss, _, _, _, _ = loss_utils.optical_flow_loss(pred_v_of, faces_of, cam, flows_f,
-                                                               of_renderer, pix_to_face)   # :334-339
-            total = total + of_loss_wt * of_loss
+        total, pred_v = refine_total(renderer, solver, delta, cam, faces, masks, edts_barrier, boundaries,
+                                     mask_loss_wt, boundaries_reg_wt, edt_reg_wt, bdt_reg_wt, of_loss_wt,
+                                     optical_flows, of_renderer, num_frames)
         opt.zero_grad(set_to_none=True)
         total.backward()
         opt.step()

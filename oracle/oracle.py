@@ -41,9 +41,10 @@ def build(force=False):
 
 
 def lib():
+    """ACFM_ORACLE_SO: an alternative build of the same C file (the ASan/UBSan build of `make asan-test`)."""
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        _LIB = ctypes.CDLL(os.environ.get("ACFM_ORACLE_SO") or build())
     return _LIB
 
 
@@ -542,3 +543,185 @@ def correlation(f1, f2, md):
         for ti in range(-md, md + 1):
             out[:, (tj + md) * D1 + ti + md] = (f1 * pad[:, :, md + tj:md + tj + H, md + ti:md + ti + W]).sum(1) / C
     return out.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- composed paths
+# Restatements of the reference's CALLERS of the hot path, composed from the pieces above: the camera
+# chain of the trainer (multiframe/main.py:97-138, 551-584), ShapeTrainer.forward's loss assembly
+# (:586-765) and one iteration of the test-time refinement loop (nnutils/predictor.py:287-349).  torch-CPU
+# float64 for everything smooth; the renders go through the C rasteriser (float32, like the product).
+def standardize_quaternion(q):
+    """pytorch3d.transforms.standardize_quaternion: non-negative real part."""
+    return torch.where(q[..., :1] < 0, -q, q)
+
+
+def quaternion_multiply(a, b):
+    """pytorch3d.transforms.quaternion_multiply (0.3.0): Hamilton product (real first), then standardise."""
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    out = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                       aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+    return standardize_quaternion(out)
+
+
+def mirrored_pose(sfm_pose):
+    """main.py:97-110 / 113-122 without the blend: (s, -tx, ty, q_mirror * standardize(q)).  q_mirror =
+    matrix_to_quaternion(diag(-1, 1, -1)) = (0, 0, 1, 0) (0.5 sqrt(max(0, 1 - m00 + m11 - m22)) = 1 on y,
+    the other three square roots vanish)."""
+    q = standardize_quaternion(sfm_pose[:, -4:])
+    qm = torch.tensor([0.0, 0.0, 1.0, 0.0], dtype=sfm_pose.dtype).expand_as(q)
+    return torch.cat([sfm_pose[:, :1], -sfm_pose[:, 1:2], sfm_pose[:, 2:3], quaternion_multiply(qm, q)], -1)
+
+
+def camera_pipeline(cam_emb, mirror_flag, transforms, scale_lr_decay=1.0):
+    """Camera embeddings [G,N,7] -> cam_pred [G*N,7] (main.py:564-584 with :113-138):
+    scales = relu(decay * e0 + 1) + 1e-12, quats normalised; mirror_cameras blended by the frame's flag
+    (repeated over the G hypotheses); transform_cameras blended by the transform's flag."""
+    G, N, _ = cam_emb.shape
+    scales = torch.relu(scale_lr_decay * cam_emb[..., :1] + 1) + 1e-12
+    quats = torch.nn.functional.normalize(cam_emb[..., 3:], dim=-1)
+    cam = torch.cat([scales, cam_emb[..., 1:3], quats], dim=2).reshape(G * N, 7)
+    mf = mirror_flag.repeat(G)[:, None].to(cam.dtype)
+    cam = (1 - mf) * cam + mirrored_pose(cam) * mf
+    tr = transforms.repeat(G, 1).to(cam.dtype)
+    flag = tr[:, -1:]
+    new = torch.cat([cam[:, :1] * tr[:, :1], cam[:, 1:2] * tr[:, :1] + tr[:, 1:2],
+                     cam[:, 2:3] * tr[:, :1] + tr[:, 2:3], cam[:, -4:]], -1)
+    return (1 - flag) * cam + new * flag
+
+
+def texture_cycle_loss(textures, num_frames):
+    """main.py:705-711, literally (the reshape to [-1,R,R] regroups the trailing (R,T,3) block as written)."""
+    t_c = textures.reshape(-1, num_frames, *textures.shape[1:]).permute(0, 2, 3, 4, 1, 5)
+    t_c = t_c.reshape(-1, t_c.shape[2], t_c.shape[3])
+    return torch.norm(t_c[:, :-1] - t_c[:, 1:], p=2, dim=-1).mean()
+
+
+def masked_texture_mse(tex, img, mask):
+    """The MSE part of the texture loss (main.py:655-662); the LPIPS part is out of scope."""
+    m = mask[:, None]
+    return ((tex * m - img * m) ** 2).mean((1, 2, 3))
+
+
+DEFAULT_OPTS = dict(num_frames=2, kp_loss_wt=0., of_loss_wt=1., mask_loss_wt=1., rigid_wt=0.5, deform_reg_wt=1.,
+                    handle_deform_reg_wt=0., boundaries_reg_wt=1., edt_reg_wt=0.1, bdt_reg_wt=2.,
+                    triangle_reg_wt=0.1, tex_loss_wt=.5, scale_lr_decay=0.05)   # main.py:55-89
+
+
+def _f64(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+def multiframe_forward_terms(cam_emb, mirror_flag, transforms, lbs_logits, mean_v, faces, delta, masks,
+                             edts_barrier, boundaries, optical_flows=None, textures=None, imgs=None, **opts):
+    """ShapeTrainer.forward (main.py:523-765) between the network heads and the loss scalar, every named term.
+    cam_emb [G,N,7] (camera embeddings of the N = B*T frames), mirror_flag [N], transforms [N,4],
+    lbs_logits [V,Kh], mean_v [V,3], faces [F,3], delta [N,Kh,3] (= delta_v_res; drop_deform: zeros),
+    masks [N,H,H], edts_barrier [N,1,H,H], boundaries [N,P,3], optical_flows [B,T,H,H,2],
+    textures [N,F,R,R,3], imgs [N,3,H,H].  Returns a dict of float64 tensors / numpy arrays."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    T = o["num_frames"]
+    cam_emb, transforms, delta, masks, edts, bds = map(_f64, (cam_emb, transforms, delta, masks, edts_barrier,
+                                                              boundaries))
+    mirror_flag = torch.as_tensor(np.asarray(mirror_flag)).long()
+    lbs_logits, mean_v = _f64(lbs_logits), _f64(mean_v)
+    faces_t = torch.as_tensor(np.asarray(faces)).long()
+    G, N, _ = cam_emb.shape
+    H = masks.shape[-1]
+    B = N // T
+    out = {}
+    cam = camera_pipeline(cam_emb, mirror_flag, transforms, o["scale_lr_decay"])          # :564-584
+    out["cam_pred"] = cam
+    L = laplacian_cot(mean_v, faces_t)                                                      # :600-601
+    pred_v1 = deform_solve(lbs_logits, mean_v, delta, L)                                    # :586-609
+    out["pred_v"] = pred_v1
+    pred_v = pred_v1.repeat(G, 1, 1)                                                        # :610
+    pv32, cam32 = pred_v.float().numpy(), cam.float().numpy()
+    faces_np = faces_t.numpy()
+    mask_pred, p2f = sil_render(pv32, faces_np, cam32, H)                                   # :637-640
+    mp = torch.from_numpy(mask_pred).double()
+    out["mask_pred"], out["pix_to_face"] = mask_pred, p2f
+    mask_loss = l1_loss(mp, masks.repeat(G, 1, 1), reduce=False).reshape(G, N)              # :644-645
+    total = o["mask_loss_wt"] * mask_loss
+    if o["of_loss_wt"] > 0 and optical_flows is not None:                                   # :664-688
+        flows = _f64(optical_flows)
+        masks_of = masks.reshape(B, T, H, H)
+        flows_f = (torch.flip(flows, dims=[1]) * masks_of[..., None]).repeat(G, 1, 1, 1, 1)
+        faces_of = faces_t[None, None].expand(G * B, T, -1, -1)
+        of_loss = optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, flows_f, None, reduce=False)[0]
+        of_loss = of_loss.reshape(G, -1).repeat(1, T).reshape(G, -1)                        # :684-686
+    else:
+        of_loss = torch.zeros(1, dtype=torch.float64)
+    out["of_loss"] = of_loss
+    total = total + o["of_loss_wt"] * of_loss
+    proj = project_torch(pred_v, cam)[..., :2]                                              # :714
+    edt = edt_loss(mp, edts.repeat(G, 1, 1, 1), reduce=False).reshape(G, N)                 # :715-716
+    bdt = bds_loss(proj, bds.repeat(G, 1, 1), faces_t[None].expand(G * N, -1, -1),
+                   torch.from_numpy(p2f), reduce=False).reshape(G, N)                       # :717-719
+    sil_cons = o["edt_reg_wt"] * edt + o["bdt_reg_wt"] * bdt                                # :721
+    total = total + o["boundaries_reg_wt"] * sil_cons
+    out.update(mask_loss=mask_loss, edt_loss=edt, bdt_loss=bdt, sil_cons=sil_cons)
+    cycle = torch.zeros((), dtype=torch.float64)
+    if textures is not None and imgs is not None:                                           # :616-636, 647-662
+        tex, im = _f64(textures), _f64(imgs)
+        atl_rep = np.ascontiguousarray(np.tile(tex.float().numpy(), (G, 1, 1, 1, 1)))
+        tp, _, _, _ = tex_render(pv32, faces_np, cam32, atl_rep, H)
+        cam_f = mirrored_pose(cam)
+        tpf, _, _, _ = tex_render(pv32, faces_np, cam_f.float().numpy(), atl_rep, H)
+        im_f, m_f = torch.flip(im, dims=(3,)), torch.flip(masks, dims=(2,))
+        tex_mse = 0.5 * (masked_texture_mse(torch.from_numpy(tp).double(), im.repeat(G, 1, 1, 1), masks.repeat(G, 1, 1))
+                         + masked_texture_mse(torch.from_numpy(tpf).double(), im_f.repeat(G, 1, 1, 1),
+                                              m_f.repeat(G, 1, 1)))
+        tex_mse = tex_mse.reshape(G, N)
+        total = total + o["tex_loss_wt"] * tex_mse
+        cycle = texture_cycle_loss(tex, T)                                                  # :705-711
+        out.update(tex_mse=tex_mse, texture_pred=tp, texture_pred_flip=tpf, cycle=cycle)
+    out["total_per_hyp"] = total
+    out["camera_loss"] = total.mean()                                                       # :734
+    probs = torch.softmax(-total, dim=0)                                                    # :735
+    weighted = (total * probs).sum(0).mean()                                                # :743-745
+    edges = torch.from_numpy(edges_packed(faces_np))
+    rigid = locally_rigid(pred_v, mean_v[None].repeat(G * N, 1, 1), edges)                  # :713 (mean over meshes)
+    triangle = laplacian_smoothing_cot(pred_v, faces_t)                                     # :702-703
+    handle = deform_l2reg(delta)                                                            # :612
+    loss = weighted + o["rigid_wt"] * rigid + o["triangle_reg_wt"] * triangle \
+        + o["deform_reg_wt"] * cycle + o["handle_deform_reg_wt"] * handle                   # :747-751
+    out.update(probs=probs, weighted=weighted, rigid=rigid, triangle=triangle, handle=handle, loss=loss)
+    return out
+
+
+def refine_iteration(lbs_logits, mean_v, faces, delta, cam_raw, masks, edts_barrier, boundaries, mask_loss_wt=1.0,
+                     boundaries_reg_wt=1.0, edt_reg_wt=0.1, bdt_reg_wt=0.1, optimize_camera=True):
+    """One iteration of the post-processing loop (predictor.py:301-345), loss and gradients:
+    cam = (s, t, normalize(q)); pred_v = solve(delta); mask render; total = mask_wt * l1 + bds_wt *
+    (bdt_reg_wt * edt_loss + edt_reg_wt * bdt_loss) (sic, :322).  Returns (total, d total / d delta,
+    d total / d cam_raw, dict of the terms).  The raster / blend backward is the C oracle's, the rest
+    float64 autograd."""
+    lbs_logits, mean_v, masks, edts, bds = map(_f64, (lbs_logits, mean_v, masks, edts_barrier, boundaries))
+    faces_t = torch.as_tensor(np.asarray(faces)).long()
+    delta = _f64(delta).clone().requires_grad_(True)
+    cam_raw = _f64(cam_raw).clone().requires_grad_(True)
+    N, H = masks.shape[0], masks.shape[-1]
+    cam = torch.cat([cam_raw[:, :3], torch.nn.functional.normalize(cam_raw[:, 3:], dim=-1)], 1) \
+        if optimize_camera else cam_raw
+    L = laplacian_cot(mean_v, faces_t)
+    pred_v = deform_solve(lbs_logits, mean_v, delta, L)
+    pv32, cam32, faces_np = pred_v.detach().float().numpy(), cam.detach().float().numpy(), faces_t.numpy()
+    mask_pred, p2f = sil_render(pv32, faces_np, cam32, H)
+    mp = torch.from_numpy(mask_pred).double().requires_grad_(True)
+    mask_loss = l1_loss(mp, masks)
+    edt = edt_loss(mp, edts)
+    proj = project_torch(pred_v, cam)[..., :2]
+    bdt = bds_loss(proj, bds, faces_t[None].expand(N, -1, -1), torch.from_numpy(p2f))
+    mask_terms = mask_loss_wt * mask_loss + boundaries_reg_wt * bdt_reg_wt * edt
+    total = mask_terms + boundaries_reg_wt * edt_reg_wt * bdt
+    gm, = torch.autograd.grad(mask_terms, mp)
+    gv, gc, _, _ = sil_render_backward(pv32, faces_np, cam32, H, gm.float().numpy())
+    # the mask terms reach delta / cam_raw through the render's vertex and camera gradients (gv, gc);
+    # the boundary term through the projection
+    surrogate = boundaries_reg_wt * edt_reg_wt * bdt + (pred_v * torch.from_numpy(gv).double()).sum() \
+        + (cam * torch.from_numpy(gc).double()).sum()
+    g_delta, g_cam = torch.autograd.grad(surrogate, [delta, cam_raw])
+    return total.detach(), g_delta, g_cam, dict(mask_loss=mask_loss.detach(), edt_loss=edt.detach(),
+                                                bdt_loss=bdt.detach(), pred_v=pred_v.detach(), mask_pred=mask_pred)

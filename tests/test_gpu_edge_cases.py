@@ -31,6 +31,10 @@ def _check_sil(verts, f, cams, H, K=20, check_bwd=True, seed=0):
         sv, sc = max(np.abs(gv).max(), 1e-20), max(np.abs(gc).max(), 1e-20)
         np.testing.assert_allclose(tv.grad.cpu().numpy(), gv, rtol=1e-4, atol=1e-4 * sv)
         np.testing.assert_allclose(tc.grad.cpu().numpy(), gc, rtol=1e-4, atol=1e-4 * sc)
+        # relative L2 beside the max-scaled bar: entries far below the largest one count too
+        for got, want in ((tv.grad.cpu().numpy(), gv), (tc.grad.cpu().numpy(), gc)):
+            rel = np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want.astype(np.float64)), 1e-30)
+            assert rel < 1e-5, rel
     return ref_p2f
 
 

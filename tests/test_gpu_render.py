@@ -421,3 +421,85 @@ def test_silhouette_backward_twice_on_one_workspace(meshes):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
     assert float((g1[1] - g3).abs().max()) <= 1e-5 * float(g3.abs().max())
     assert float(g1[0].abs().max()) > 0
+
+
+def test_setup_take_over_never_crosses_a_graph_replay_or_a_stream(meshes):
+    """Eager silhouette render -> a hipGraph replay rewrites the vertex buffer in place (no version bump) -> eager
+    texture render of the same tensor: the cached face setup must NOT be taken over (ops._EPOCH is bumped by every
+    CUDAGraph.replay); the result is the oracle's render of the NEW geometry.  Likewise a texture render on another
+    stream, and after ops.invalidate_setups() / with share_setup(False), sets up by itself."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = _dev()
+    n, H = 2, 64
+    verts_a, f, cams = _setup(meshes, "bird", n, 61)
+    verts_b = (verts_a + np.array([0.08, -0.05, 0.0], np.float32)).astype(np.float32)
+    rng = np.random.default_rng(62)
+    atlas = torch.tensor(rng.uniform(0, 1, (n, f.shape[0], 2, 2, 3)).astype(np.float32), device=d)
+    tf = torch.from_numpy(f).to(d)[None].repeat(n, 1, 1).contiguous()
+    tc = torch.tensor(cams, device=d)
+    tv = torch.zeros(n, verts_a.shape[1], 3, device=d)
+    src = torch.tensor(verts_a, device=d)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        tv.copy_(src)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        tv.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    ops.sil_render(tv, tf, tc, H)
+    assert ops._shared_setup(tv, tc, tf, H, 0.0) is not None             # plain eager pair: shared
+    ver = tv._version
+    src.copy_(torch.tensor(verts_b, device=d))
+    g.replay()                                                           # tv now holds verts_b, same address, same version
+    torch.cuda.synchronize()
+    assert tv._version == ver and np.array_equal(tv.cpu().numpy(), verts_b)
+    assert ops._shared_setup(tv, tc, tf, H, 0.0) is None
+    imgs, sil, p2f = ops.tex_render(tv, tf, tc, atlas, H)
+    ri, rs, rp, _ = O.tex_render(verts_b, f, cams, atlas.cpu().numpy(), H)
+    np.testing.assert_array_equal(p2f.cpu().numpy(), rp)
+    np.testing.assert_allclose(imgs.cpu().numpy(), ri, atol=1e-6)
+    assert (rp != O.tex_render(verts_a, f, cams, atlas.cpu().numpy(), H)[2]).any()   # the stale setup would have shown
+    # another stream: the texture render is not ordered behind the silhouette render -> own setup
+    ops.sil_render(tv, tf, tc, H)
+    assert ops._shared_setup(tv, tc, tf, H, 0.0) is not None
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        assert ops._shared_setup(tv, tc, tf, H, 0.0) is None
+        out2 = ops.tex_render(tv, tf, tc, atlas, H)
+    torch.cuda.current_stream().wait_stream(s2)
+    np.testing.assert_array_equal(out2[2].cpu().numpy(), rp)
+    # explicit controls
+    ops.sil_render(tv, tf, tc, H)
+    ops.invalidate_setups()
+    assert ops._shared_setup(tv, tc, tf, H, 0.0) is None
+    old = ops.share_setup(False)
+    try:
+        ops.sil_render(tv, tf, tc, H)
+        assert ops._shared_setup(tv, tc, tf, H, 0.0) is None
+    finally:
+        ops.share_setup(old)
+    # inside ONE capture the pair shares (replayed together, in order); the result replays correctly on new geometry
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ops.sil_render(tv, tf, tc, H)
+            ops.tex_render(tv, tf, tc, atlas, H)
+    torch.cuda.current_stream().wait_stream(s)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        m_c, _ = ops.sil_render(tv, tf, tc, H)
+        shared_in_capture = ops._shared_setup(tv, tc, tf, H, 0.0) is not None
+        i_c, _, p_c = ops.tex_render(tv, tf, tc, atlas, H)
+    assert shared_in_capture
+    assert ops._shared_setup(tv, tc, tf, H, 0.0) is None                 # ... but not from outside the capture
+    src.copy_(torch.tensor(verts_a, device=d))
+    g.replay()
+    g2.replay()
+    torch.cuda.synchronize()
+    ra = O.tex_render(verts_a, f, cams, atlas.cpu().numpy(), H)
+    np.testing.assert_array_equal(p_c.cpu().numpy(), ra[2])
+    np.testing.assert_allclose(i_c.cpu().numpy(), ra[0], atol=1e-6)
