@@ -12,6 +12,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef ACFM_FWD_V2
+#define ACFM_FWD_V2 0   // see acfm_raster.hip
+#endif
+
 #define ACFM_K_EPS 1e-8f   // PyTorch3D kEpsilon
 #define ACFM_EYE_Z 2.732f  // nmr.py:144: eye=(0,0,-2.732) -> T=(0,0,2.732)
 #define ACFM_WAVE 64
@@ -36,11 +40,24 @@ struct ProfScope {
 };
 
 // Per-face record of the raster workspace (k_setup writes it, the binning of the raster kernels reads it).
+// Two cache lines: the first is all the backward walk needs; the second holds what is constant per FACE in the
+// exact per-pixel test -- the three edge vectors, their squared lengths and refined reciprocals (the operands
+// of the IEEE-exact divisions of point_line_dist / the barycentrics) -- computed once per face in k_setup
+// with the very operations the per-pixel code used to repeat for every pixel, so every per-pixel value is
+// bit-identical to the unfactored evaluation (and to the oracle).
 struct __attribute__((aligned(64))) FaceRec {
   float4 box;   // (xmin,xmax,ymin,ymax), blur margin included; degenerate face = (inf,-inf,inf,-inf)
   float4 a;     // (x0,y0,x1,x2)   -- (x1,x2), (y1,y2) as register pairs for the packed fp32 pipe
   float4 b;     // (y1,y2,z0,z1)
-  float4 c;     // (z2, area, -, -)
+  float4 c;     // (z2, area, denom = area + kEps, rden = refined 1/denom)
+#if ACFM_FWD_V2   // (second cache line: only the per-pixel-list experiment reads it)
+  float4 e01;   // (x1-x0, y1-y0, |.|^2, refined 1/|.|^2)      edge v0 -> v1
+  float4 e12;   // (x2-x1, y2-y1, |.|^2, refined 1/|.|^2)      edge v1 -> v2
+  float4 e02;   // (x2-x0, y2-y0, |.|^2, refined 1/|.|^2)      edge v0 -> v2
+  float4 sn;    // (s01, s12, s02, flag): s = -sign(area) / |edge| (0 for an edge shorter than 1e-6): edge function
+                // x s = signed distance of the pixel to the edge LINE, positive outside -- the conservative
+                // per-pixel prefilter of the forward kernels; flag = 1 if an edge has |.|^2 <= kEps
+#endif
 };
 
 // Workspace carve-up shared by every raster entry point (acfm_raster_workspace_bytes).

@@ -36,6 +36,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 namespace acfm {
 
@@ -145,7 +146,25 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     r.box = b;
     r.a = make_float4(x0, y0, x1, x2);
     r.b = make_float4(y1, y2, z0, z1);
-    r.c = make_float4(z2, area, 0.f, 0.f);
+    {
+      const float denom = area + ACFM_K_EPS;
+      r.c = make_float4(z2, area, denom, recip_refined(denom));
+#if ACFM_FWD_V2
+      const float sgn = area > 0.f ? -1.0f : 1.0f;
+      float s3[3], flag = 0.f;
+      const float ex[3] = {x1 - x0, x2 - x1, x2 - x0}, ey[3] = {y1 - y0, y2 - y1, y2 - y0};
+      float4 e[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float l2 = ex[k] * ex[k] + ey[k] * ey[k];
+        e[k] = make_float4(ex[k], ey[k], l2, recip_refined(l2));
+        s3[k] = l2 > 1e-12f ? sgn * __builtin_amdgcn_rsqf(l2) : 0.f;
+        if (l2 <= ACFM_K_EPS) flag = 1.0f;
+      }
+      r.e01 = e[0]; r.e12 = e[1]; r.e02 = e[2];
+      r.sn = make_float4(s3[0], s3[1], s3[2], flag);
+#endif
+    }
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
     ws.fvis[o] = 0;
     if (!degenerate) {
@@ -820,7 +839,9 @@ __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, c
 #ifndef ACFM_FAST_SIGMOID
 #define ACFM_FAST_SIGMOID 1
 #endif
-__device__ __forceinline__ float sigmoid_scale(float sigma) { return 1.44269504088896341f / sigma; }
+__device__ __forceinline__ float sigmoid_scale(float sigma) {   // wave-uniform: kept in an SGPR
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.44269504088896341f / sigma)));
+}
 __device__ __forceinline__ float sigmoid_neg_fast(float sd, float sigma, float scale) {
 #if ACFM_FAST_SIGMOID
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sd * scale));
@@ -854,6 +875,8 @@ struct FwdOut {
   float gamma;
   float box_shrink;          // > 0: the workspace was set up with a larger blur margin; boxes are tightened by this much
   int atlas_n;               // number of distinct atlases: mesh n samples atlas n % atlas_n
+  float sig_scale;           // log2(e) / sigma (sigmoid_scale), computed on the host: a kernel argument can be re-read
+                             // from the kernarg segment with a scalar load where a computed value would be spilled
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -907,7 +930,34 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
 // (5.5 KB: the register budget, not LDS, then bounds the waves per SIMD -- measured on the
 // backward: 13.8 KB -> 6.9 KB per wave = 292 -> 256 us); the K-nearest kernels are register-bound
 // at 3-4 waves per SIMD anyway and need 64 K 8 bytes to stage the block's face ids.
-template <int CAP, int MIN_BYTES>
+// forward walk: 0 = 4x4-group sub-lists (walk_wave, the shipping kernels); 1 = per-pixel candidate lists
+// (pix_lists_walk): an experiment kept for reference -- correct (all parity tests and the sweep pass) but
+// slower: 359 vs 258 us on the 64-frame bird launch.  Every lane walks its own list, so a wave-iteration always
+// pays the whole body (nothing is ever skipped wave-wide), all 64 lanes insert different faces at different
+// list positions (nearly every 4-slot block of the sorted insertion executes, 270 vs ~140 ns per iteration),
+// and max-over-64-lanes of the list lengths (~25) is not much below max-over-4-groups (~30).
+#ifndef ACFM_FWD_V2
+#define ACFM_FWD_V2 0
+#endif
+// LDS of the per-pixel-list forward walk: PCAP candidate records of 128 bytes (the whole FaceRec), one byte list
+// per pixel (slot-major: list[i][lane], so a wave reads its i-th entries from 64 consecutive bytes) and the face-id
+// list of the coarse tile, whose front doubles as the queue of ids that passed the block's box test.
+// Records are 7 x 16 B = 28 dwords apart (the box lives in its own array): in the main loop every lane reads ITS
+// candidate's record with ds_read_b128, 16 lanes per LDS cycle, bank = dword address mod 64 -- with a stride of 32
+// dwords all candidates would sit on two bank groups (measured: 16-way conflicts, the walk 1.6x slower than the
+// one it replaces); 28 = 4 x 7 spreads 16 consecutive candidates over all 16 four-bank groups, and lanes on the
+// same candidate broadcast.
+template <int PCAP>
+struct PixLds {
+  static constexpr int CAP = PCAP;
+  float4 rec[PCAP][7];           // a, b, c (c.y = face id), e01, e12, e02, sn
+  float4 box[PCAP];
+  unsigned char list[PCAP][64];
+  fl_t fl[FLCAP];
+};
+constexpr int PCAP_SOFT = 48;   // 6144 + 3072 + 1024 = 10240 B = the K = 20 id staging area: 16 waves per CU
+constexpr int PCAP_HARD = 32;   // 4096 + 2048 + 1024 = 7168 B
+template <int CAP, int PCAP, int MIN_BYTES>
 struct FwdLdsT {
   struct Lists {
     CandListT<CAP> L;
@@ -915,11 +965,253 @@ struct FwdLdsT {
     unsigned short wl[2 * CAP];   // the wave's list of the edge cull, and the same in depth order
   };
   union {
+#if ACFM_FWD_V2
+    PixLds<PCAP> p;
+#else
     Lists s;
+#endif
     char stage[MIN_BYTES > 16 ? MIN_BYTES : 16];   // the block's K ids in image order (the lists are dead by then)
   };
 };
-template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? RCAP : 64), (K > 1 ? 64 * K * 8 : 0)>;
+template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? RCAP : 64), (K > 1 ? PCAP_SOFT : PCAP_HARD), (K > 1 ? 64 * K * 8 : 0)>;
+
+#if ACFM_FWD_V2
+// ------------------------------------------------------------------------------- per-pixel lists
+// Exact per-pixel test on a candidate RECORD (FaceRec with its per-face constants).  Same operations in the
+// same order as test_face_depth / test_face_dist / the oracle for everything that depends on the pixel; what
+// depends on the face alone (edge vectors, squared lengths, refined reciprocals) comes from the record.
+//   edge_fn(p; v1, v2) = (px - x1)(y2 - y1) - (py - y1)(x2 - x1)                      = dx1 e12.y - dy1 e12.x
+//   edge_fn(p; v2, v0) = (px - x2)(y0 - y2) - (py - y2)(x0 - x2) = -(dx2 e02.y) + dy2 e02.x  (negations are exact)
+//   edge_fn(p; v0, v1) = (px - x0)(y1 - y0) - (py - y0)(x1 - x0)                      = dx0 e01.y - dy0 e01.x
+struct PixD { float dx0, dy0, dx1, dy1, dx2, dy2; };
+__device__ __forceinline__ PixD pix_deltas(float px, float py, const float4& a, const float4& b) {
+  PixD d;
+  d.dx0 = px - a.x; d.dy0 = py - a.y; d.dx1 = px - a.z; d.dy1 = py - b.x; d.dx2 = px - a.w; d.dy2 = py - b.y;
+  return d;
+}
+template <bool CLIP, bool INSIDE_ONLY = false>
+__device__ __forceinline__ bool rec_depth(const PixD& d, const float4& b, const float4& c, const float4& e01,
+                                          const float4& e12, const float4& e02, Hit& h, bool& inside) {
+  const float n0 = d.dx1 * e12.y - d.dy1 * e12.x;
+  const float n1 = d.dy2 * e02.x - d.dx2 * e02.y;
+  const float n2 = d.dx0 * e01.y - d.dy0 * e01.x;
+  const float denom = c.z, r = c.w;
+  const float w0 = div_by(n0, denom, r), w1 = div_by(n1, denom, r), w2 = div_by(n2, denom, r);
+  float c0 = w0, c1 = w1, c2 = w2;
+  inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  if (INSIDE_ONLY && !inside) return false;
+  if (CLIP) {
+    c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
+    c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
+    c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    const float rs = recip_refined(s);
+    c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
+  }
+  const float pz = c0 * b.z + c1 * b.w + c2 * c.x;
+  h.pz = pz; h.c0 = c0; h.c1 = c1; h.c2 = c2;
+  return !(pz < 0.0f);
+}
+// squared distance to the segment a + t e, (dxa, dya) = p - a; e = (ex, ey, |e|^2, refined 1/|e|^2), |e|^2 > kEps
+__device__ __forceinline__ float rec_seg_dist(float px, float py, float ax, float ay, float dxa, float dya, const float4& e) {
+  float t = div_by(e.x * dxa + e.y * dya, e.z, e.w);
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float qx = ax + t * e.x, qy = ay + t * e.y;
+  const float dx = qx - px, dy = qy - py;
+  return dx * dx + dy * dy;
+}
+__device__ __forceinline__ bool rec_dist(float px, float py, const PixD& d, const float4& a, const float4& b,
+                                         const float4& e01, const float4& e12, const float4& e02, bool degenerate,
+                                         float blur, bool inside, Hit& h) {
+  if (degenerate) {   // an edge with |e|^2 <= kEps (rare): the unfactored evaluation with its distance-to-endpoint branch
+    h.d01 = point_line_dist(px, py, a.x, a.y, a.z, b.x);
+    h.d02 = point_line_dist(px, py, a.x, a.y, a.w, b.y);
+    h.d12 = point_line_dist(px, py, a.z, b.x, a.w, b.y);
+  } else {
+    h.d01 = rec_seg_dist(px, py, a.x, a.y, d.dx0, d.dy0, e01);
+    h.d02 = rec_seg_dist(px, py, a.x, a.y, d.dx0, d.dy0, e02);
+    h.d12 = rec_seg_dist(px, py, a.z, b.x, d.dx1, d.dy1, e12);
+  }
+  const float dm = fminf(fminf(h.d01, h.d02), h.d12);
+  h.sd = inside ? -dm : dm;
+  return inside || !(dm >= blur);
+}
+
+// Forward walk with PER-PIXEL candidate lists.  The block's faces are binned exactly as in bin_and_walk (coarse-tile
+// bitmask -> id list -> box test against the 8x8 block, 64 ids per round), but the ids that pass are queued and
+// handled in chunks of CAP: (1) CAP lanes copy the chunk's 128-byte records into LDS; (2) [ORDER] the chunk is dealt
+// into 8 depth classes so that lists fill roughly front to back; (3) PREFILTER, lane = pixel, one candidate per
+// iteration for the whole wave (uniform LDS reads): the three edge functions of the pixel -- the exact test's own
+// operations -- scaled to line distances say whether the pixel can possibly be accepted (blur == 0: inside <=> all
+// three have the sign of the area; blur > 0: no edge line farther than sqrt(blur) (+ slack) outside, and inside the
+// blur-expanded box); a pixel that can is given the candidate's index in ITS list; (4) MAIN loop, lane = pixel,
+// every lane walks its own list: the exact test runs only on (pixel, face) pairs that are almost surely accepted,
+// each lane on a different face.  Against the 4x4-group walk (walk_wave: ~25 faces per group for 13 kept per pixel,
+// a wave-iteration as long as one lane survives) the wave runs max-over-lanes(list length) iterations of the
+// expensive body instead of max-over-groups(faces met), and nothing of it is spent on pairs the prefilter rejects.
+// The prefilter is conservative: it never rejects a pair the exact test accepts (slack 1e-3 sqrt(blur), four orders
+// above the rounding of an edge function), so results are unchanged -- the lists only decide what is looked at.
+// Split role (t.sub >= 0: 16 pixels x 4 quarter-waves): quarter s takes the candidates j = s (mod 4) of the chunk.
+// body(have, c) is called for every lane of the wave: `have` = the lane has an entry this iteration, c = its
+// candidate's index into P.rec.
+template <bool INSIDE_PREFILTER, bool ORDER, int CAP, class Body>
+__device__ __forceinline__ void pix_lists_walk(const RasterWs& ws, const Tile& t, int F, int H, float blur,
+                                               float box_shrink, PixLds<CAP>& P, Body&& body) {
+  if (t.empty) return;  // flagged by k_order: no face box near this block
+  float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
+#pragma unroll
+  for (int i = 1; i < SETUP_SLICES; ++i) {
+    const float4 m2 = ws.mbox[(size_t)t.n * SETUP_SLICES + i];
+    mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
+  }
+  if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
+  const unsigned long long lt = (1ull << t.lane) - 1ull;
+  const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
+  const int cty = (t.yi & ~7) / CTILE, ctx = (t.xi & ~7) / CTILE;
+  const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(ws.cmask) +
+                                   ((size_t)t.n * ctiles * ctiles + (size_t)cty * ctiles + ctx) * words;
+  fl_t* s_fl = P.fl;
+  const float r_cull = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sqrtf(blur) * 1.001f)));
+  const bool split = t.sub >= 0;
+  const int quarter = t.lane >> 4;
+
+  // one chunk of n <= CAP queued ids (s_fl[0 .. n)): records -> LDS, order, prefilter, main loop
+  auto chunk = [&](int n) {
+    if (t.lane < n) {
+      const int f = (int)s_fl[t.lane];
+      const float4* g = reinterpret_cast<const float4*>(&ws.rec[(size_t)t.n * F + f]);
+      float4 r0 = g[0], r1 = g[1], r2 = g[2], r3 = g[3], r4 = g[4], r5 = g[5], r6 = g[6], r7 = g[7];
+      r0.x += box_shrink; r0.y -= box_shrink; r0.z += box_shrink; r0.w -= box_shrink;
+      r3.y = __int_as_float(f);                  // (area itself is not used by the record path: denom and its reciprocal are)
+      float4* o = P.rec[t.lane];
+      P.box[t.lane] = r0;
+      o[0] = r1; o[1] = r2; o[2] = r3; o[3] = r4; o[4] = r5; o[5] = r6; o[6] = r7;
+    }
+    wave_lds_sync();
+    int ordreg = t.lane;                          // lane j: the candidate visited j-th
+    if (ORDER && n > 8) {
+      // front to back, roughly: 8 depth classes by the face's nearest vertex (counting sort with ballots); the order
+      // never changes a result, it changes how far a new face has to travel in the sorted per-pixel lists
+      const float INF = __builtin_inff();
+      const bool live = t.lane < n;
+      const float z = live ? min3f(P.rec[t.lane][1].z, P.rec[t.lane][1].w, P.rec[t.lane][2].x) : INF;
+      const float zlo = wave_min(z), zhi = wave_max(live ? z : -INF);
+      const float sc = 8.0f / fmaxf(zhi - zlo, 1e-12f);
+      const int cls = live ? min(7, (int)((z - zlo) * sc)) : 8;
+      int base = 0, pos = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) pos = base + __popcll(m & lt);
+        base += __popcll(m);
+      }
+      unsigned char* tmp = &P.list[0][0];         // (free until the prefilter fills it)
+      if (live) tmp[pos] = (unsigned char)t.lane;
+      wave_lds_sync();
+      ordreg = live ? (int)tmp[t.lane] : 0;
+      wave_lds_sync();
+    }
+    // prefilter: lane = pixel, candidates one by one
+    int cnt = 0;
+    unsigned char* mylist = &P.list[0][t.lane];
+#pragma unroll 1
+    for (int j = 0; j < n; ++j) {
+      const int c = __builtin_amdgcn_readlane(ordreg, j);
+      const float4* R = P.rec[c];
+      const float4 a = R[0], b = R[1];
+      const float4 e01 = R[3], e12 = R[4], e02 = R[5], sn = R[6];
+      const PixD d = pix_deltas(t.xf, t.yf, a, b);
+      const float n0 = d.dx1 * e12.y - d.dy1 * e12.x;
+      const float n1 = d.dy2 * e02.x - d.dx2 * e02.y;
+      const float n2 = d.dx0 * e01.y - d.dy0 * e01.x;
+      // signed distances to the three edge LINES, positive outside (edge function x (-sign(area) / |edge|))
+      const float o = max3f(n0 * sn.y, n1 * sn.z, n2 * sn.x);
+      bool keep;
+      if (INSIDE_PREFILTER) {
+        keep = !(o > 0.0f);                       // inside <=> every edge function has the sign of the area (o < 0)
+      } else {
+        const float4 box = P.box[c];
+        keep = !(o > r_cull) && !((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z));
+      }
+      keep = keep && t.valid && (!split || (j & 3) == quarter);
+      if (keep) mylist[cnt * 64] = (unsigned char)c;
+      cnt += keep ? 1 : 0;
+    }
+    wave_lds_sync();
+    int maxlen = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+#pragma unroll 1
+    for (int i = 0; i < maxlen; ++i) {
+      const bool have = i < cnt;
+      const int c = have ? (int)mylist[i * 64] : 0;
+      body(have, c);
+    }
+    wave_lds_sync();
+  };
+
+  // One loop with a single chunk() site (its body holds the per-pixel top-K lists in registers: a second inlined
+  // copy costs registers).  State: the id list s_fl[i0 .. total) still to be tested (or the direct range
+  // [f0, fe)), and the queue of ids that passed, s_fl[0 .. pend_n), which never reaches past the read position
+  // (a round reads 64 ids into registers before it appends at most 64).
+  int pend_n = 0;
+  int w0 = -64, total = 0, i0 = 0, f0 = 0, fe = 0;
+  bool direct = false;
+#pragma unroll 1
+  for (;;) {
+    const bool exhausted = !(direct ? f0 < fe : i0 < total);
+    if (pend_n >= CAP || (exhausted && pend_n > 0)) {
+      const int n = min(pend_n, CAP);
+      chunk(n);
+      const int rest = pend_n - n;                // < 64: a round adds at most 64 to a queue shorter than CAP
+      const fl_t v = t.lane < rest ? s_fl[n + t.lane] : (fl_t)0;
+      wave_lds_sync();
+      if (t.lane < rest) s_fl[t.lane] = v;
+      wave_lds_sync();
+      pend_n = rest;
+      continue;
+    }
+    if (exhausted) {                              // (the queue is empty here) next 4096 faces of the coarse tile's mask
+      w0 += 64;
+      if (w0 >= words) break;
+      unsigned long long m = (w0 + t.lane < words) ? mrow[w0 + t.lane] : 0ull;
+      const int cnt = __popcll(m);
+      const int incl = wave_inclusive_scan(cnt, t.lane);
+      total = __builtin_amdgcn_readlane(incl, 63);
+      i0 = 0;
+      direct = total > FLCAP;  // a coarse tile crowded beyond the id list: test these 4096 faces directly
+      if (direct) {
+        f0 = w0 * 64; fe = min(F, (w0 + 64) * 64); total = 0;
+      } else if (total > 0) {
+        int pos = incl - cnt;
+        const int fbase = (w0 + t.lane) * 64;
+#pragma unroll 1
+        while (m != 0ull) {
+          s_fl[pos++] = (fl_t)(fbase + (int)__ffsll((long long)m) - 1);
+          m &= m - 1ull;
+        }
+        wave_lds_sync();
+      }
+      continue;
+    }
+    int f;
+    if (direct) { f = (f0 + t.lane < fe) ? f0 + t.lane : -1; f0 += RT; }
+    else { f = (i0 + t.lane < total) ? (int)s_fl[i0 + t.lane] : -1; i0 += RT; }
+    bool pass = false;
+    if (f >= 0) {
+      float4 b = ws.rec[(size_t)t.n * F + f].box;
+      b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
+      pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) s_fl[pend_n + __popcll(bal & lt)] = (fl_t)f;
+    pend_n += __popcll(bal);
+    wave_lds_sync();
+  }
+}
+
+#endif  // ACFM_FWD_V2
 
 // Constant outputs of a flagged-empty 8x8 block (no face box comes near it): exactly what
 // fwd_block leaves for a block without candidates.  Lane i owns pixel (i / 8, i % 8) of the block;
@@ -962,8 +1254,10 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
 template <int K, bool CLIP, bool TEX>
 __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
                                           const FwdOut& out, FwdLdsK<K>& S) {
+#if !ACFM_FWD_V2
   auto& L = S.s.L;
   fl_t* s_fl = S.s.fl;
+#endif
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
 
@@ -974,6 +1268,34 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     // so the three edge distances decide nothing; only the winner's signed distance is ever used
     // (the blend weight of the texture branch) and is evaluated once per pixel after the walk.
     const bool dist_late = !(blur > 0.0f);
+#if ACFM_FWD_V2
+    auto& P = S.p;
+    auto body1 = [&](bool have, int c, auto late) {
+      if (!have) return;
+      const float4* R = P.rec[c];
+      const float4 box = P.box[c], a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
+      // (the oracle's box test; with blur = 0 it is implied by `inside` up to rounding, and kept for that reason)
+      if ((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z)) return;
+      const PixD d = pix_deltas(t.xf, t.yf, a, b);
+      Hit h;
+      h.sd = 0.f;
+      bool inside = false;
+      if (decltype(late)::value) {
+        if (!rec_depth<CLIP, true>(d, b, cc, e01, e12, e02, h, inside)) return;
+      } else {
+        if (!rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside)) return;
+        if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
+      }
+      const unsigned long long key = make_key(h.pz, __float_as_int(cc.y));
+      if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
+    };
+    if (dist_late)
+      pix_lists_walk<true, false>(ws, t, F, H, blur, out.box_shrink, P,
+                                  [&](bool have, int c) { body1(have, c, std::true_type()); });
+    else
+      pix_lists_walk<false, false>(ws, t, F, H, blur, out.box_shrink, P,
+                                   [&](bool have, int c) { body1(have, c, std::false_type()); });
+#else
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
@@ -990,6 +1312,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
       });
     });
+#endif
     if (!t.valid) return;
     const bool hit = (bestkey != KEY_NONE);
     const int f = (int)(bestkey & 0xffffffffu);
@@ -1053,13 +1376,34 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     // registers.  A new face is bubbled through the array with compare-exchanges on static
     // register indices (the displaced farthest entry falls off the end), so there is no LDS or
     // memory list, no final sort and the kept set is exactly the K nearest at every moment.
-    unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
-    const float sig_scale = sigmoid_scale(sigma);
+    const float sig_scale = out.sig_scale;
     unsigned long long key[K];
     float q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
+#if ACFM_FWD_V2
+    auto& P = S.p;
+    pix_lists_walk<false, true>(ws, t, F, H, blur, out.box_shrink, P, [&](bool have, int c) {
+      const float4* R = P.rec[c];
+      const float4 a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
+      const PixD d = pix_deltas(t.xf, t.yf, a, b);
+      // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list cannot enter it
+      // (empty slots hold ~0, so x < key[K-1] is always true for a list that is not full yet)
+      Hit h;
+      bool inside = false;
+      bool live = have && rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside);
+      unsigned long long x = make_key(h.pz, __float_as_int(cc.y));
+      live = live && (x < key[K - 1]);
+      seen += 1;
+      if (__ballot(live) == 0ull) return;
+      if (!live) return;
+      if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
+      float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma, sig_scale);
+      bubble_insert<K, 0>(key, q, x, xq, __builtin_amdgcn_readfirstlane(seen));
+    });
+#else
+    unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
 #ifdef ACFM_DIAG_NO_WALK
       if (list_n >= 0) { seen += list_n; return; }
@@ -1094,6 +1438,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       });
       seen += list_n;
     });
+#endif
     const bool split = t.sub >= 0;
     if (split) {
       // The four 16-lane groups hold the K nearest of their quarter of the candidates for the same
@@ -1811,6 +2156,7 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   out.kth = reinterpret_cast<unsigned long long*>(kth);
   out.vis = vis;
   out.V = V;
+  out.sig_scale = 1.44269504088896341f / sigma;
   switch (K) {
     case 20: return launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st);
     case 10: return launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, tn, st);
