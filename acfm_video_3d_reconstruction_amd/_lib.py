@@ -45,6 +45,10 @@ SIGNATURES = {
                               _sz, _vp, _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
                                _sz, _i, _vp, _vp]),
+    "acfm_sil_loss_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _sz, _vp, _vp]),
+    "acfm_sil_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _vp,
+                                    _vp, _vp, _sz, _i, _vp, _vp]),
     "acfm_hard_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "acfm_tex_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
                               _vp, _sz, _i, _f, _i, _vp, _vp]),
@@ -52,6 +56,9 @@ SIGNATURES = {
                                        _i, _f, _vp, _vp]),
     "acfm_tex_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_tex_backward_faces": (_i, [_vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_mse_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _sz, _i, _f, _i, _vp, _vp]),
+    "acfm_tex_mse_backward_faces": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_combine_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_combine_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -877,6 +877,16 @@ struct FwdOut {
   int atlas_n;               // number of distinct atlases: mesh n samples atlas n % atlas_n
   float sig_scale;           // log2(e) / sigma (sigmoid_scale), computed on the host: a kernel argument can be re-read
                              // from the kernarg segment with a scalar load where a computed value would be spilled
+  // fused render + silhouette losses (acfm_sil_loss_forward): the block's partial sums of the loss terms leave
+  // with the mask; lpart == null: plain render
+  const float* lgt;          // [lrb,H,H] ground-truth masks (may be null)
+  const float* ledt;         // [lrb,H,H] distance transforms (may be null)
+  int lrb;                   // references: mesh n is compared with reference n % lrb
+  float4* lpart;             // [N,blocks^2,4] (ws.lpart)
+  // fused texture render + masked MSE (acfm_tex_mse_forward): lpart[..].x takes the block's sum of
+  // (tex m - img m)^2 - (img m)^2 over its covered pixels (elsewhere tex = 0 and the difference vanishes)
+  const float* timg;         // [lrb,3,H,H] reference images
+  const float* tmask;        // [lrb,H,H] reference masks
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -1222,6 +1232,10 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
   const bool valid = (yi < H) && (xi < H);
   const size_t pix = ((size_t)n * H + yi) * H + xi;
   if constexpr (K == 1) {
+    if (TEX && out.lpart && lane == 0) {
+      const int tiles = (H + RBLK - 1) / RBLK;
+      out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (!valid) return;
     out.p2f[pix] = (int64_t)-1;
     if (TEX) {
@@ -1236,6 +1250,10 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
       out.mask[pix] = 0.0f;
       if (out.kth) out.kth[pix] = KEY_NONE;
       if (out.kout == 1) out.p2f[pix] = (long long)-1;
+    }
+    if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
+      const int tiles = (H + RBLK - 1) / RBLK;
+      out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (out.kout == 1) return;
     typedef long long ll2 __attribute__((ext_vector_type(2)));
@@ -1313,7 +1331,8 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       });
     });
 #endif
-    if (!t.valid) return;
+    float tacc = 0.f;     // fused texture MSE: this pixel's (tex m - img m)^2 - (img m)^2 over the three channels
+    if (t.valid) {
     const bool hit = (bestkey != KEY_NONE);
     const int f = (int)(bestkey & 0xffffffffu);
     if (TEX && dist_late && hit) {
@@ -1363,12 +1382,28 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
           const float* tx3 = out.atlas + ti * 3;
           cr = tx3[0]; cg = tx3[1]; cb = tx3[2];
         }
-        img[0] = (wnum * cr + delta * 0.0f) / den;
-        img[HW] = (wnum * cg + delta * 0.0f) / den;
-        img[2 * HW] = (wnum * cb + delta * 0.0f) / den;
+        const float vr = (wnum * cr + delta * 0.0f) / den, vg = (wnum * cg + delta * 0.0f) / den,
+                    vb = (wnum * cb + delta * 0.0f) / den;
+        img[0] = vr; img[HW] = vg; img[2 * HW] = vb;
         out.sil[t.pix] = 1.0f - (1.0f - prob);
         out.tidx[t.pix] = (int32_t)ti;
         ws.fvis[(size_t)n * F + f] = 1;   // the atlas gradient (k_tex_bwd_faces) visits only faces that were seen
+        if (out.lpart) {
+          const size_t pp = (size_t)t.yi * H + t.xi, rn = (size_t)(n % out.lrb);
+          const float mk = out.tmask[rn * HW + pp];
+          const float* ri = out.timg + rn * 3 * HW + pp;
+          const float b0 = ri[0] * mk, b1 = ri[HW] * mk, b2 = ri[2 * HW] * mk;
+          const float d0 = vr * mk - b0, d1 = vg * mk - b1, d2 = vb * mk - b2;
+          tacc = (d0 * d0 - b0 * b0) + (d1 * d1 - b1 * b1) + (d2 * d2 - b2 * b2);
+        }
+      }
+    }
+    }   // t.valid
+    if (TEX && out.lpart) {
+      tacc = wave_sum(tacc);
+      if (t.lane == 0) {
+        const int tiles = (H + RBLK - 1) / RBLK;
+        out.lpart[(((size_t)n * tiles + t.yi / RBLK) * tiles + t.xi / RBLK) * 4] = make_float4(tacc, 0.f, 0.f, 0.f);
       }
     }
   } else {
@@ -1461,19 +1496,43 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       }
     }
     const bool out_valid = t.valid && (!split || t.lane < 16);
+    float lmask = 0.f, lg = 0.f, le = 0.f;
+    if (out.lpart && out_valid) {
+      const size_t rp = t.pix - (size_t)n * H * H + (size_t)(n % out.lrb) * H * H;
+      if (out.lgt) lg = out.lgt[rp];
+      if (out.ledt) le = out.ledt[rp];
+    }
     if (out_valid) {
       float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
 #pragma unroll
       for (int k = 0; k < K; ++k) alpha = alpha * q[k];
       out.mask[t.pix] = 1.0f - alpha;
       if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
+      lmask = 1.0f - alpha;
       if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
       // lean output: only the nearest-face plane, the one slot any caller of the reference
       // reads (loss_utils.py:214, 431); the other K-1 ids stay in registers
       if (out.kout == 1)
         out.p2f[t.pix] = (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1;
     }
-    if (out.kout == 1) return;
+    // Fused silhouette losses: with m = 0 outside the blocks that have work, sum|m - g| = sum g + sum(|m - g| - g),
+    // sum(m + g - m g) = sum g + sum(m - m g); the finish kernels add sum g.  One 16-byte store per block (and
+    // split role), no atomics: the per-mesh sums are formed in fixed order (deterministic).  Called last, after the
+    // block's ids are on their way: the references were requested before the outputs (lg, le above).
+    auto losses_out = [&]() {
+      if (!out.lpart) return;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      if (out_valid) { t0 = fabsf(lmask - lg) - lg; t1 = lmask * lg; t2 = lmask - lmask * lg; t3 = le * lmask; }
+      t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3);
+      if (t.lane < 4) {
+        const int tiles = (H + RBLK - 1) / RBLK;
+        // (yi / 8, xi / 8 are the block's own for every lane)
+        const size_t slot = (((size_t)n * tiles + t.yi / RBLK) * tiles + t.xi / RBLK) * 4;
+        if (split) { if (t.lane == 0) out.lpart[slot + t.sub] = make_float4(t0, t1, t2, t3); }
+        else out.lpart[slot + t.lane] = t.lane == 0 ? make_float4(t0, t1, t2, t3) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    if (out.kout == 1) { losses_out(); return; }
     typedef long long ll2 __attribute__((ext_vector_type(2)));  // K even -> 16-byte pieces
     constexpr int CH = K / 2;                                   // pieces per pixel
     constexpr bool STAGED = sizeof(FwdLdsK<K>) >= (size_t)64 * K * 8;
@@ -1501,8 +1560,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         if (by + r < H && bx + off / CH < H)
           reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
       }
-    } else {
-      if (!out_valid) return;
+    } else if (out_valid) {
       ll2* o2 = reinterpret_cast<ll2*>(out.p2f + t.pix * K);
 #pragma unroll
       for (int k2 = 0; k2 < CH; ++k2) {
@@ -1512,6 +1570,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         o2[k2] = v;
       }
     }
+    losses_out();
   }
 }
 
@@ -1588,9 +1647,19 @@ __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax
 #endif
 constexpr int BWD_CAP = ACFM_BWD_CAP;   // candidate-list capacity of the backward (LDS per wave: 108 B per slot)
 using BwdList = CandListT<BWD_CAP>;
+// Upstream gradient of the mask: either given per pixel (grad_mask) or, for the fused render+loss operator,
+// formed on the fly from the references and the per-mesh gradients of the four loss terms -- k_mask_losses_bwd's
+// expression, operation for operation: go0 sign(m - g) / HW + go1 g + go2 (1 - g) + go3 e / HW.
+struct BwdGrad {
+  const float* grad_mask;    // [N,H,H], or null: fused
+  const float* lgt;          // [lrb,H,H] (may be null)
+  const float* ledt;         // [lrb,H,H] (may be null)
+  const float* go;           // [N,4]
+  int lrb;
+};
 __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const float* __restrict__ mask,
                                               const unsigned long long* __restrict__ kth,
-                                              const float* __restrict__ grad_mask, int V, int F, int H, float blur,
+                                              const BwdGrad& bg, int V, int F, int H, float blur,
                                               float sigma, BwdList& L, fl_t* s_fl, float (*s_acc)[6]) {
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
@@ -1601,7 +1670,21 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   if (t.valid) {
     const float m = mask[t.pix];
     if (m != 0.0f) {
-      coef = -grad_mask[t.pix] * (1.0f - m) / sigma;
+      float gm;
+      if (bg.grad_mask) {
+        gm = bg.grad_mask[t.pix];
+      } else {
+        const size_t HW = (size_t)H * H;
+        const size_t rp = t.pix - (size_t)t.n * HW + (size_t)(t.n % bg.lrb) * HW;
+        const float g = bg.lgt ? bg.lgt[rp] : 0.f, e = bg.ledt ? bg.ledt[rp] : 0.f;
+        const float inv = 1.0f / (float)HW;
+        const float* go = bg.go + 4 * (size_t)t.n;
+        const float g0 = go[0] * inv, g1 = go[1], g2 = go[2], g3 = go[3] * inv;
+        const float df = m - g;
+        const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+        gm = g0 * sgn + g1 * g + g2 * (1.0f - g) + g3 * e;
+      }
+      coef = -gm * (1.0f - m) / sigma;
       kthkey = kth[t.pix];
     }
   }
@@ -1682,7 +1765,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
 
 __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
-                                                 const float* __restrict__ grad_mask, int N, int V,
+                                                 BwdGrad grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {
   __shared__ BwdList L;
   __shared__ fl_t s_fl[FLCAP];
@@ -1698,6 +1781,129 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
     if (!t.none) sil_bwd_block(ws, t, mask, kth, grad_mask, V, F, H, blur, sigma, L, s_fl, s_acc);
     wave_lds_sync();
   }
+}
+
+// Fused render + loss, finish: per mesh, the block partials of the raster kernel and sum(gt) over the whole image
+// (the blocks without work have m = 0: |m - g| = g, m + g - m g = g) -> out[n] = (mean|m - g|, sum m g,
+// sum(m + g - m g), mean e m), the [N,4] vector of k_mask_losses.  Two short launches, FIN_CHUNKS workgroups per mesh
+// in the first (one workgroup per mesh was latency-bound: 45 us for 64 meshes); every sum is formed in a fixed
+// order (thread-strided partial sums, a fixed tree, then the chunks in order): deterministic, no atomics.
+constexpr int FIN_CHUNKS = 8;
+__global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restrict__ lpart, const float* __restrict__ gt,
+                                                           int tt, int HW, int RB, float* __restrict__ part2) {
+  __shared__ float s_red[TPB][5];
+  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, gs = 0.f;
+  const float4* p = lpart + (size_t)n * tt * 4;
+  const int np = tt * 4, p_lo = (int)((long long)np * ch / FIN_CHUNKS), p_hi = (int)((long long)np * (ch + 1) / FIN_CHUNKS);
+  for (int i = p_lo + tid; i < p_hi; i += TPB) {
+    const float4 v = p[i];
+    a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+  }
+  if (gt) {
+    const float* g = gt + (size_t)(n % RB) * HW;
+    if ((HW & 3) == 0) {
+      const int q = HW / 4, q_lo = (int)((long long)q * ch / FIN_CHUNKS), q_hi = (int)((long long)q * (ch + 1) / FIN_CHUNKS);
+      constexpr int U = 8;                       // loads of a round in flight together
+      for (int i0 = q_lo + tid; i0 < q_hi; i0 += TPB * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * TPB;
+          v[u] = i < q_hi ? reinterpret_cast<const float4*>(g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) gs += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      }
+    } else {
+      const int g_lo = (int)((long long)HW * ch / FIN_CHUNKS), g_hi = (int)((long long)HW * (ch + 1) / FIN_CHUNKS);
+      for (int i = g_lo + tid; i < g_hi; i += TPB) gs += g[i];
+    }
+  }
+  s_red[tid][0] = a0; s_red[tid][1] = a1; s_red[tid][2] = a2; s_red[tid][3] = a3; s_red[tid][4] = gs;
+  __syncthreads();
+  for (int s = TPB / 2; s > 0; s >>= 1) {
+    if (tid < s)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s_red[tid][k] += s_red[tid + s][k];
+    __syncthreads();
+  }
+  if (tid < 5) part2[((size_t)n * FIN_CHUNKS + ch) * 5 + tid] = s_red[0][tid];
+}
+__global__ void k_sil_loss_finish2(const float* __restrict__ part2, int N, int HW, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < FIN_CHUNKS; ++c)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a[k] += part2[((size_t)n * FIN_CHUNKS + c) * 5 + k];
+  const float hw = (float)HW;
+  out[4 * (size_t)n + 0] = (a[4] + a[0]) / hw;
+  out[4 * (size_t)n + 1] = a[1];
+  out[4 * (size_t)n + 2] = a[4] + a[2];
+  out[4 * (size_t)n + 3] = a[3] / hw;
+}
+
+// Fused texture render + masked MSE, finish: out[n] = (sum over the mesh's blocks of their partial
+// + sum_c sum_px (img_c m)^2) / (3 HW) -- the second term is what an uncovered pixel (tex = 0) contributes.
+__global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restrict__ lpart, const float* __restrict__ timg,
+                                                           const float* __restrict__ tmask, int tt, int HW, int RB,
+                                                           float* __restrict__ part2) {
+  __shared__ float s_red[TPB];
+  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;
+  const float4* p = lpart + (size_t)n * tt * 4;
+  const int t_lo = (int)((long long)tt * ch / FIN_CHUNKS), t_hi = (int)((long long)tt * (ch + 1) / FIN_CHUNKS);
+  for (int i = t_lo + tid; i < t_hi; i += TPB) acc += p[4 * (size_t)i].x;
+  const size_t rn = (size_t)(n % RB);
+  const float* m = tmask + rn * HW;
+  const float* im = timg + rn * 3 * HW;
+  if ((HW & 3) == 0) {
+    const int q = HW / 4, q_lo = (int)((long long)q * ch / FIN_CHUNKS), q_hi = (int)((long long)q * (ch + 1) / FIN_CHUNKS);
+    constexpr int U = 4;
+    for (int i0 = q_lo + tid; i0 < q_hi; i0 += TPB * U) {
+      float4 mk[U], c0[U], c1[U], c2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * TPB;
+        const bool in = i < q_hi;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        mk[u] = in ? reinterpret_cast<const float4*>(m)[i] : z;
+        c0[u] = in ? reinterpret_cast<const float4*>(im)[i] : z;
+        c1[u] = in ? reinterpret_cast<const float4*>(im + HW)[i] : z;
+        c2[u] = in ? reinterpret_cast<const float4*>(im + 2 * (size_t)HW)[i] : z;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        auto sq = [](float a, float b) { const float v = a * b; return v * v; };
+        acc += (sq(c0[u].x, mk[u].x) + sq(c1[u].x, mk[u].x) + sq(c2[u].x, mk[u].x)) +
+               (sq(c0[u].y, mk[u].y) + sq(c1[u].y, mk[u].y) + sq(c2[u].y, mk[u].y)) +
+               (sq(c0[u].z, mk[u].z) + sq(c1[u].z, mk[u].z) + sq(c2[u].z, mk[u].z)) +
+               (sq(c0[u].w, mk[u].w) + sq(c1[u].w, mk[u].w) + sq(c2[u].w, mk[u].w));
+      }
+    }
+  } else {
+    const int g_lo = (int)((long long)HW * ch / FIN_CHUNKS), g_hi = (int)((long long)HW * (ch + 1) / FIN_CHUNKS);
+    for (int i = g_lo + tid; i < g_hi; i += TPB) {
+      const float mk = m[i];
+      const float b0 = im[i] * mk, b1 = im[HW + i] * mk, b2 = im[2 * (size_t)HW + i] * mk;
+      acc += b0 * b0 + b1 * b1 + b2 * b2;
+    }
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int s = TPB / 2; s > 0; s >>= 1) {
+    if (tid < s) s_red[tid] += s_red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) part2[(size_t)n * FIN_CHUNKS + ch] = s_red[0];
+}
+__global__ void k_tex_loss_finish2(const float* __restrict__ part2, int N, int HW, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int c = 0; c < FIN_CHUNKS; ++c) a += part2[(size_t)n * FIN_CHUNKS + c];
+  out[n] = a / (3.0f * (float)HW);
 }
 
 // ------------------------------------------------------------------------------- projection
@@ -1821,7 +2027,39 @@ __device__ __forceinline__ void divmod_small(int i, int w, float rw, int& q, int
 constexpr int TEXG_MAX_R = 8;
 constexpr int TEXG_FPW = 4;      // faces per wave: their boxes, texel indices and gradients are loaded side by side
 constexpr int TEXG_U = 8;        // big boxes: 64 U pixels per round, all their loads in flight together
-__global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float* __restrict__ grad_imgs,
+// Upstream gradient of the rendered image: given ([N,3,H,H]) or, for the fused texture render + masked MSE, formed
+// on the fly from the rendered image, the reference image and mask and the per-mesh gradient of the loss --
+// k_tex_mse_bwd's expression: w (tex m - img m) m with w = go[n] 2 / (3 HW).
+struct TexGrad {
+  const float* grad_imgs;    // [N,3,H,H], or null: fused
+  const float* imgs;         // [N,3,H,H] the forward's output
+  const float* timg;         // [rb,3,H,H]
+  const float* tmask;        // [rb,H,H]
+  const float* go;           // [N]
+  int rb;
+};
+struct TexGradN {            // the same for one mesh n
+  const float *g, *ri, *rm;
+  float w;
+  size_t HW;
+  __device__ __forceinline__ void load(size_t p, float& r, float& gg, float& b) const {
+    if (!rm) { r = g[p]; gg = g[HW + p]; b = g[2 * HW + p]; return; }
+    const float mk = rm[p];
+    r = w * (g[p] * mk - ri[p] * mk) * mk;
+    gg = w * (g[HW + p] * mk - ri[HW + p] * mk) * mk;
+    b = w * (g[2 * HW + p] * mk - ri[2 * HW + p] * mk) * mk;
+  }
+};
+__device__ __forceinline__ TexGradN tex_grad_of(const TexGrad& tg, int n, size_t HW) {
+  TexGradN t;
+  t.HW = HW;
+  if (tg.grad_imgs) { t.g = tg.grad_imgs + (size_t)n * 3 * HW; t.ri = nullptr; t.rm = nullptr; t.w = 0.f; return t; }
+  const size_t rn = (size_t)(n % tg.rb);
+  t.g = tg.imgs + (size_t)n * 3 * HW; t.ri = tg.timg + rn * 3 * HW; t.rm = tg.tmask + rn * HW;
+  t.w = tg.go[n] * 2.0f / (3.0f * (float)HW);
+  return t;
+}
+__global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, TexGrad tgrad,
                                                        const int32_t* __restrict__ tidx, int N, int F, int H,
                                                        int R, int NA, float box_shrink,
                                                        float* __restrict__ grad_atlas) {
@@ -1871,7 +2109,7 @@ __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float*
       }
     }
     const int32_t* tn = tidx + (size_t)n * HW;
-    const float* gn = grad_imgs + (size_t)n * 3 * HW;
+    const TexGradN gn = tex_grad_of(tgrad, n, HW);
     int cmax = 0;
     int t[TEXG_FPW];
     size_t pp[TEXG_FPW];
@@ -1893,7 +2131,8 @@ __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float*
     for (int k = 0; k < TEXG_FPW; ++k) {                     // ... then the gradients of the pixels that belong to the face
       if (t[k] >= 0 && t[k] < R2) {
         // d rgb / d texel = wnum / (wnum + delta) = 1 in fp32 (wnum >= 0.5, delta = 1e-10)
-        const float r = gn[pp[k]], gg = gn[HW + pp[k]], bb = gn[2 * HW + pp[k]];
+        float r, gg, bb;
+        gn.load(pp[k], r, gg, bb);
         atomicAdd(&acc[k][3 * t[k] + 0], r);
         atomicAdd(&acc[k][3 * t[k] + 1], gg);
         atomicAdd(&acc[k][3 * t[k] + 2], bb);
@@ -1916,7 +2155,7 @@ __global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, const float*
               divmod_small(i, kw, rw, qy, qx);
               const size_t p = (size_t)(kya + qy) * H + (kxa + qx);
               tt[u] = tn[p] - kbase;
-              cr[u] = gn[p]; cg[u] = gn[HW + p]; cb[u] = gn[2 * HW + p];   // unconditionally: one round trip per round
+              gn.load(p, cr[u], cg[u], cb[u]);                              // unconditionally: one round trip per round
             }
           }
 #pragma unroll
@@ -2133,11 +2372,13 @@ int acfm_project_xy_backward(const float* verts, const float* cams, const float*
   return ACFM_OK;
 }
 
-int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
-                     int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
-                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
-                     size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream) {
+static int sil_forward_impl(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
+                            int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
+                            float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                            size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream, bool fused,
+                            const float* gt, const float* edt, int ref_batch, float* losses) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
+  if (fused && (!losses || ref_batch <= 0 || N % ref_batch != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
       (k_out != K && k_out != 1))
     return ACFM_E_BADARG;
@@ -2157,23 +2398,51 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
   out.vis = vis;
   out.V = V;
   out.sig_scale = 1.44269504088896341f / sigma;
+  out.lrb = 1;
+  if (fused) { out.lgt = gt; out.ledt = edt; out.lrb = ref_batch; out.lpart = ws.lpart; }
   switch (K) {
-    case 20: return launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st);
-    case 10: return launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, tn, st);
-    case 8: return launch_sil_fwd<8>(ws, N, F, H, blur_radius, sigma, out, tn, st);
-    case 4: return launch_sil_fwd<4>(ws, N, F, H, blur_radius, sigma, out, tn, st);
-    case 2: return launch_sil_fwd<2>(ws, N, F, H, blur_radius, sigma, out, tn, st);
-    case 32: return launch_sil_fwd<32>(ws, N, F, H, blur_radius, sigma, out, tn, st);
+    case 20: rc = launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
+    case 10: rc = launch_sil_fwd<10>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
+    case 8: rc = launch_sil_fwd<8>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
+    case 4: rc = launch_sil_fwd<4>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
+    case 2: rc = launch_sil_fwd<2>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
+    case 32: rc = launch_sil_fwd<32>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
     default: return ACFM_E_BADARG;  // supported K: 2, 4, 8, 10, 20, 32
   }
+  if (rc || !fused) return rc;
+  const int tiles = (H + RBLK - 1) / RBLK;
+  ProfScope ps(ACFM_PROF_MASK_LOSS, st);
+  hipLaunchKernelGGL(k_sil_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, gt, tiles * tiles, H * H,
+                     ref_batch, ws.lpart2);
+  hipLaunchKernelGGL(k_sil_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, losses);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
 }
 
-int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
-                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
-                      int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
-                      float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
-                      const AcfmRasterTuning* tuning, void* stream) {
-  if (!verts_world || !faces || !cams || !mask || !kth || !grad_mask || !wsp) return ACFM_E_BADARG;
+int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
+                     int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
+                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                     size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream) {
+  return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
+                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr);
+}
+
+int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* gt,
+                          const float* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                          float blur_radius, float sigma, float offset_z, float* mask, int64_t* pix_to_face,
+                          uint64_t* kth, uint8_t* vis, float* losses, void* wsp, size_t ws_bytes,
+                          const AcfmRasterTuning* tuning, void* stream) {
+  return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
+                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, true, gt, edt, ref_batch, losses);
+}
+
+static int sil_backward_impl(const float* verts_world, const int64_t* faces, const float* cams,
+                             const float* mask, const uint64_t* kth, const BwdGrad& bg, int N, int V,
+                             int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
+                             float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
+                             const AcfmRasterTuning* tuning, void* stream) {
+  if (!verts_world || !faces || !cams || !mask || !kth || !wsp) return ACFM_E_BADARG;
+  if (!bg.grad_mask && (!bg.go || bg.lrb <= 0 || N % bg.lrb != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
   Tune tn;
   if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
@@ -2190,7 +2459,7 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
     hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, tn.div[2], ws.split_slots)), dim3(RT), lds, st, ws, mask,
-                       reinterpret_cast<const unsigned long long*>(kth), grad_mask, N, V, F, H,
+                       reinterpret_cast<const unsigned long long*>(kth), bg, N, V, F, H,
                        blur_radius, sigma);
   }
   ACFM_CHECK_LAUNCH();
@@ -2201,6 +2470,31 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
     ACFM_CHECK_LAUNCH();
   }
   return ACFM_OK;
+}
+
+int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
+                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                      int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
+                      float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
+                      const AcfmRasterTuning* tuning, void* stream) {
+  if (!grad_mask) return ACFM_E_BADARG;
+  BwdGrad bg = {};
+  bg.grad_mask = grad_mask;
+  bg.lrb = 1;
+  return sil_backward_impl(verts_world, faces, cams, mask, kth, bg, N, V, F, H, blur_radius, sigma, offset_z,
+                           grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream);
+}
+
+int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const float* mask,
+                           const uint64_t* kth, const float* gt, const float* edt, int ref_batch,
+                           const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
+                           float offset_z, float* grad_verts, float* grad_cams, void* wsp, size_t ws_bytes,
+                           int ws_from_forward, const AcfmRasterTuning* tuning, void* stream) {
+  if (!grad_losses) return ACFM_E_BADARG;
+  BwdGrad bg = {};
+  bg.lgt = gt; bg.ledt = edt; bg.go = grad_losses; bg.lrb = ref_batch;
+  return sil_backward_impl(verts_world, faces, cams, mask, kth, bg, N, V, F, H, blur_radius, sigma, offset_z,
+                           grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream);
 }
 
 int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V, int F, int H,
@@ -2226,11 +2520,12 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
   return ACFM_OK;
 }
 
-int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
-                     const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
-                     float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
-                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
-                     const AcfmRasterTuning* tuning, void* stream) {
+static int tex_forward_impl(const float* verts_world, const int64_t* faces, const float* cams,
+                            const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
+                            float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
+                            void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
+                            const AcfmRasterTuning* tuning, void* stream, const float* ref_img,
+                            const float* ref_mask, int ref_batch, float* loss) {
   if (!verts_world || !faces || !cams || !atlas || !imgs || !sil || !pix_to_face || !texel_idx || !wsp)
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
@@ -2252,11 +2547,47 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
   out.atlas_n = atlas_batch;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
-  ProfScope ps(ACFM_PROF_TEX_FWD, st);
-  hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
-                     0.f, sigma, out);
-  ACFM_CHECK_LAUNCH();
+  out.lrb = 1;
+  if (loss) {
+    if (!ref_img || !ref_mask || ref_batch <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;
+    out.timg = ref_img; out.tmask = ref_mask; out.lrb = ref_batch; out.lpart = ws.lpart;
+  }
+  {
+    ProfScope ps(ACFM_PROF_TEX_FWD, st);
+    hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
+                       0.f, sigma, out);
+    ACFM_CHECK_LAUNCH();
+  }
+  if (loss) {
+    const int tiles = (H + RBLK - 1) / RBLK;
+    ProfScope ps(ACFM_PROF_TEX_MSE, st);
+    hipLaunchKernelGGL(k_tex_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, ref_img, ref_mask,
+                       tiles * tiles, H * H, ref_batch, ws.lpart2);
+    hipLaunchKernelGGL(k_tex_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, loss);
+    ACFM_CHECK_LAUNCH();
+  }
   return ACFM_OK;
+}
+
+int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
+                     const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
+                     float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
+                     void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
+                     const AcfmRasterTuning* tuning, void* stream) {
+  return tex_forward_impl(verts_world, faces, cams, atlas, N, V, F, H, R, sigma, gamma, offset_z, imgs, sil,
+                          pix_to_face, texel_idx, wsp, ws_bytes, ws_ready, ws_blur, atlas_batch, tuning, stream,
+                          nullptr, nullptr, 1, nullptr);
+}
+
+int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* atlas,
+                         const float* ref_img, const float* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
+                         float sigma, float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+                         int32_t* texel_idx, float* loss, void* wsp, size_t ws_bytes, int ws_ready, float ws_blur,
+                         int atlas_batch, const AcfmRasterTuning* tuning, void* stream) {
+  if (!loss) return ACFM_E_BADARG;
+  return tex_forward_impl(verts_world, faces, cams, atlas, N, V, F, H, R, sigma, gamma, offset_z, imgs, sil,
+                          pix_to_face, texel_idx, wsp, ws_bytes, ws_ready, ws_blur, atlas_batch, tuning, stream,
+                          ref_img, ref_mask, ref_batch, loss);
 }
 
 int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, const float* cams,
@@ -2306,10 +2637,10 @@ int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, i
   return ACFM_OK;
 }
 
-int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
-                            float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
-                            void* stream) {
-  if (!grad_imgs || !texel_idx || !grad_atlas || !wsp) return ACFM_E_BADARG;
+static int tex_backward_faces_impl(const TexGrad& tgrad, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
+                                   float ws_blur, int N, int V, int F, int H, int R, int atlas_batch,
+                                   float* grad_atlas, void* stream) {
+  if (!texel_idx || !grad_atlas || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > TEXG_MAX_R || atlas_batch <= 0 || N % atlas_batch != 0 || !(ws_blur >= 0.f))
     return ACFM_E_BADARG;
   if ((size_t)atlas_batch * F * R * R > 0x7fffffffull) return ACFM_E_BADARG;
@@ -2318,10 +2649,30 @@ int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, co
   hipStream_t st = (hipStream_t)stream;
   const size_t waves = (size_t)atlas_batch * ((F + TEXG_FPW - 1) / TEXG_FPW);
   ProfScope ps(ACFM_PROF_TEX_BWD, st);
-  hipLaunchKernelGGL(k_tex_bwd_faces, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ws, grad_imgs, texel_idx,
+  hipLaunchKernelGGL(k_tex_bwd_faces, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ws, tgrad, texel_idx,
                      N, F, H, R, atlas_batch, ws_blur > 0.f ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f, grad_atlas);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
+}
+
+int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
+                            float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
+                            void* stream) {
+  if (!grad_imgs) return ACFM_E_BADARG;
+  TexGrad tg = {};
+  tg.grad_imgs = grad_imgs;
+  tg.rb = 1;
+  return tex_backward_faces_impl(tg, texel_idx, wsp, ws_bytes, ws_blur, N, V, F, H, R, atlas_batch, grad_atlas, stream);
+}
+
+int acfm_tex_mse_backward_faces(const float* imgs, const float* ref_img, const float* ref_mask, int ref_batch,
+                                const float* grad_loss, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
+                                float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
+                                void* stream) {
+  if (!imgs || !ref_img || !ref_mask || !grad_loss || ref_batch <= 0 || N <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;
+  TexGrad tg = {};
+  tg.imgs = imgs; tg.timg = ref_img; tg.tmask = ref_mask; tg.go = grad_loss; tg.rb = ref_batch;
+  return tex_backward_faces_impl(tg, texel_idx, wsp, ws_bytes, ws_blur, N, V, F, H, R, atlas_batch, grad_atlas, stream);
 }
 
 }  // extern "C"

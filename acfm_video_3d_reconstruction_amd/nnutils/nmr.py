@@ -80,6 +80,28 @@ class NeuralRenderer(torch.nn.Module):
         return imgs, sil, pix_to_face
 
 
+    def forward_silhouette_losses(self, vertices, faces, cams, mask_gt, edt, eps=1e-6, raw=False):
+        """Opt-in fused operator (no reference counterpart as ONE call: it is `forward` followed by
+        loss_utils.l1_loss / iou / edt_loss, multiframe/main.py:637-645, 715-716): the loss terms leave the raster
+        kernel with the mask, the backward needs no [N,H,W] mask gradient.
+        -> ((l1 [N], iou [N], edt [N]) or the raw [N,4] vector, mask_pred (no gradient), pix_to_face)."""
+        out, masks, pix_to_face = ops.sil_render_losses(vertices, faces, cams, self.img_size, mask_gt, edt,
+                                                        K=self.faces_per_pixel, blur=self.blur_radius,
+                                                        sigma=self.sigma, offset_z=self.offset_z,
+                                                        k_out=self.pix_to_face_slots)
+        if raw:
+            return out, masks, pix_to_face
+        return (out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]), masks, pix_to_face
+
+
+    def forward_texture_mse(self, vertices, faces, cams, textures, imgs, masks):
+        """Opt-in fused operator: `forward(..., textures=...)` followed by the masked MSE of multiframe/main.py:655-662,
+        F.mse_loss(texture_pred * masks, imgs * masks, reduction='none').mean((1, 2, 3)), as one call.
+        -> (mse [N], texture_pred (no gradient), sil, pix_to_face)."""
+        return ops.tex_render_mse(vertices, faces, cams, textures.to(vertices.device), imgs, masks, self.img_size,
+                                  sigma=1e-4, gamma=1e-4, offset_z=self.offset_z)
+
+
 class OF_NeuralRenderer(torch.nn.Module):
     """nmr.py:203-238: visibility rasteriser for the optical-flow loss."""
 

@@ -473,6 +473,80 @@ def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_S
     return mask, p2f
 
 
+class _SilRenderLosses(torch.autograd.Function):
+    """acfm_sil_loss_forward / _backward: soft silhouette render + the [N,4] silhouette-loss vector as one operator."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z, k_out):
+        _lib.require_gpu(verts, faces, cams, gt, edt)
+        v, c = _f32c(verts), _f32c(cams)
+        N, V, _ = v.shape
+        f = expand_faces(faces, N)
+        F, H = f.shape[1], int(img_size)
+        g = _f32c(gt).reshape(-1, H, H) if gt is not None else None
+        e = _f32c(edt).reshape(-1, H, H) if edt is not None else None
+        RB = N
+        for r in (g, e):
+            if r is not None:
+                RB = _ref_batch(N, r, "sil_render_losses")
+        if g is not None and e is not None and g.shape[0] != e.shape[0]:
+            raise ValueError("sil_render_losses: gt and edt must have the same batch")
+        mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, k_out), dtype=torch.int64, device=v.device)
+        kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)
+        vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
+        losses = torch.empty((N, 4), dtype=torch.float32, device=v.device)
+        ws, nb = _workspace(N, V, F, H, v.device)
+        tp, tune = _lib.tuning()
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_sil_loss_forward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(g), _lib.ptr(e), RB, N, V, F, H, K, int(k_out),
+                float(blur), float(sigma), float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth),
+                _lib.ptr(vis), _lib.ptr(losses), _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)),
+                "acfm_sil_loss_forward")
+        if _SHARE[0]:
+            _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
+        ctx.save_for_backward(v, f, c, mask, kth, g, e)
+        ctx.cfg = (H, float(blur), float(sigma), float(offset_z), RB)
+        ctx.ws = (ws, nb, tune)
+        ctx.mark_non_differentiable(mask, p2f, vis)
+        ctx.set_materialize_grads(False)
+        return losses, mask, p2f, vis
+
+    @staticmethod
+    def backward(ctx, glosses, _gm, _gp, _gv):
+        v, f, c, mask, kth, g, e = ctx.saved_tensors
+        H, blur, sigma, offset_z, RB = ctx.cfg
+        N, V, _ = v.shape
+        F = f.shape[1]
+        none = (None,) * 11
+        if glosses is None:
+            return none
+        go = _f32c(glosses)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
+        ws, nb, tune = ctx.ws
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_sil_loss_backward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), _lib.ptr(e), RB,
+                _lib.ptr(go), N, V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
+                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_loss_backward")
+        return (gv, None, gc) + none[3:]
+
+
+def sil_render_losses(verts, faces, cams, img_size, gt=None, edt=None, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA,
+                      offset_z=0.0, k_out=None):
+    """Soft-silhouette render and its silhouette losses as ONE operator (opt-in; the drop-in pair is
+    sil_render + mask_losses): -> (losses [N,4] = (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m), mask [N,H,H],
+    pix_to_face [N,H,H,k_out]).  Gradients flow from `losses` to verts / cams; `mask` is returned for inspection and
+    carries none (use sil_render when the mask itself feeds further differentiable code).  gt / edt: [N,...] or
+    [N/G,...] shared by the G hypotheses of a frame."""
+    losses, mask, p2f, vis = _SilRenderLosses.apply(verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z,
+                                                    K if k_out is None else int(k_out))
+    p2f._acfm_vis = vis
+    return losses, mask, p2f
+
+
 # ------------------------------------------------------------------------------ hard raster
 def hard_raster(verts_proj, faces, img_size):
     """OF_NeuralRenderer.forward: pre-projected verts -> pix_to_face [N,H,H,1] i64."""
@@ -563,6 +637,74 @@ def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offs
     texture (mesh n samples atlas n % (N/G); equivalent to atlas.repeat(G,1,1,1,1) without the
     copies, gradients of the G renders summed)."""
     return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z)
+
+
+class _TexRenderMSE(torch.autograd.Function):
+    """acfm_tex_mse_forward / acfm_tex_mse_backward_faces: atlas render + masked MSE against reference images as one op."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z):
+        _lib.require_gpu(verts, faces, cams, atlas, ref_img, ref_mask)
+        v, c, a = _f32c(verts), _f32c(cams), _f32c(atlas)
+        ri, rm = _f32c(ref_img), _f32c(ref_mask)
+        N, V, _ = v.shape
+        f = expand_faces(faces, N)
+        F, H = f.shape[1], int(img_size)
+        NA = a.shape[0] if a.dim() == 5 else 0
+        if a.dim() != 5 or NA == 0 or N % NA != 0 or a.shape[1] != F or a.shape[2] != a.shape[3] or a.shape[4] != 3:
+            raise ValueError("atlas must be [N,F,R,R,3] (or [N/G,F,R,R,3]), got %s for N=%d F=%d" % (tuple(a.shape), N, F))
+        R = a.shape[2]
+        if R > 8:
+            raise ValueError("tex_render_mse: atlas resolution R <= 8 (use tex_render + tex_mse beyond)")
+        RB = _ref_batch(N, ri, "tex_render_mse")
+        if ri.shape[1:] != (3, H, H) or rm.reshape(-1, H, H).shape[0] != RB:
+            raise ValueError("ref_img [N or N/G,3,H,H] and ref_mask [same batch,H,H]")
+        rm = rm.reshape(RB, H, H)
+        imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
+        sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+        tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
+        loss = torch.empty((N,), dtype=torch.float32, device=v.device)
+        shared = _shared_setup(v, c, f, H, offset_z)
+        if shared is not None:
+            ws, nb, ws_blur, tune = shared
+        else:
+            ws, nb = _workspace(N, V, F, H, v.device)
+            ws_blur, tune = 0.0, _lib.tuning()[1]
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_tex_mse_forward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), _lib.ptr(ri), _lib.ptr(rm), RB, N, V, F, H, R,
+                float(sigma), float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
+                _lib.ptr(tidx), _lib.ptr(loss), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
+                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_mse_forward")
+        ctx.save_for_backward(tidx, imgs, ri, rm)
+        ctx.cfg = (N, F, H, R, NA, V, RB)
+        ctx.ws = (ws, nb, float(ws_blur))
+        ctx.mark_non_differentiable(imgs, sil, p2f)
+        ctx.set_materialize_grads(False)
+        return loss, imgs, sil, p2f
+
+    @staticmethod
+    def backward(ctx, gloss, _gi, _gs, _gp):
+        tidx, imgs, ri, rm = ctx.saved_tensors
+        N, F, H, R, NA, V, RB = ctx.cfg
+        ga = None
+        if ctx.needs_input_grad[3] and gloss is not None:
+            g = _f32c(gloss)
+            ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=g.device)
+            ws, nb, ws_blur = ctx.ws
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.lib().acfm_tex_mse_backward_faces(
+                    _lib.ptr(imgs), _lib.ptr(ri), _lib.ptr(rm), RB, _lib.ptr(g), _lib.ptr(tidx), _lib.ptr(ws), nb,
+                    ws_blur, N, V, F, H, R, NA, _lib.ptr(ga), _lib.cur_stream(g.device)), "acfm_tex_mse_backward_faces")
+        return (None, None, None, ga) + (None,) * 6
+
+
+def tex_render_mse(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
+    """Atlas-textured render and its masked MSE against reference images as ONE operator (opt-in; the drop-in pair is
+    tex_render + tex_mse): -> (loss [N] = mean over (3,H,W) of (tex*mask - img*mask)^2, imgs [N,3,H,H] (no gradient),
+    sil, pix_to_face).  Gradient flows from `loss` to the atlas.  ref_img / ref_mask: [N,...] or [N/G,...]."""
+    return _TexRenderMSE.apply(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z)
 
 
 def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):

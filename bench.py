@@ -128,7 +128,7 @@ def main():
 
     side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
 
-    def compute(ren):
+    def compute(ren, fused=False):
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
         tex_term = None
         if side is not None:
@@ -139,8 +139,11 @@ def main():
             with torch.cuda.stream(side):
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
                 tex_term = 0.5 * L.masked_texture_mse(tex, imgs_gt, gt_mask).mean()  # main.py:655-662
-        mask, p2f = ren(pred_v, faces, cams)                             # a3
-        sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)   # a10, a11: [N,4] = (l1, ., ., edt)
+        if fused:   # opt-in operator: the loss terms leave the raster kernel with the mask (acfm_sil_loss_*)
+            sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_mask, edt, raw=True)
+        else:
+            mask, p2f = ren(pred_v, faces, cams)                             # a3
+            sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)   # a10, a11: [N,4] = (l1, ., ., edt)
         proj = ren.project_points(pred_v, cams)                          # a2
         bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
         # total = mean_n(l1 + 0.1 edt + 0.1 bds) [+ 0.5 mean_n(texture mse)]: one launch each way
@@ -149,8 +152,11 @@ def main():
             torch.cuda.current_stream(dev).wait_stream(side)
             total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1]) + tex_term
         elif a.tex:
-            tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
-            tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)                   # main.py:655-662
+            if fused:
+                tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_gt, gt_mask)[0]
+            else:
+                tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
+                tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)                   # main.py:655-662
             total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
         else:
             total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1])
@@ -171,12 +177,12 @@ def main():
         else:
             mean_p.grad = g_mean
 
-    def step(ren=renderer):
-        total, g_delta, g_cams, g_mean, g_atlas = compute(ren)
+    def step(ren=renderer, fused=False):
+        total, g_delta, g_cams, g_mean, g_atlas = compute(ren, fused)
         exchange(total, g_mean)
         return total, g_delta, g_cams, g_atlas
 
-    def graphed(ren):
+    def graphed(ren, fused=False):
         """The same step with its ~60 launches (forward, backward, every gradient buffer) captured
         once into a hipGraph and replayed: shapes are static, every entry point of libacfm_hip.so is
         stream-ordered, so the step runs at the GPU's pace whatever the host's launch rate is (with
@@ -187,12 +193,12 @@ def main():
         s2.wait_stream(cur)
         with torch.cuda.stream(s2):
             for _ in range(3):
-                compute(ren)
+                compute(ren, fused)
         cur.wait_stream(s2)
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            outs = compute(ren)
+            outs = compute(ren, fused)
 
         def replay(_ren=None):
             g.replay()
@@ -208,12 +214,12 @@ def main():
 
     graph_note = []
 
-    def timed(ren, warmup, steps, use_graph=None):
+    def timed(ren, warmup, steps, use_graph=None, fused=False):
         use_graph = (not a.eager and side is None) if use_graph is None else use_graph
-        fn = step
+        fn = (lambda r: step(r, True)) if fused else step
         if use_graph:
             try:
-                fn = graphed(ren)
+                fn = graphed(ren, fused)
             except Exception as exc:   # never lose the measurement to a capture problem: fall back, and say so
                 torch.cuda.synchronize()
                 graph_note.append("capture failed (%s: %s), eager launch instead" % (type(exc).__name__, str(exc)[:200]))
@@ -243,6 +249,10 @@ def main():
     if not a.no_lean:
         lean = NeuralRenderer(H, pix_to_face_slots=1)
         dt_lean = timed(lean, max(2, a.warmup // 2), a.steps)
+
+    # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
+    # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
+    dt_fused = timed(renderer, max(2, a.warmup // 2), a.steps, fused=True) if side is None else None
 
     # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
     # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
@@ -435,6 +445,13 @@ def main():
                 "note": "headline step + per-step factorisation of the deformation system with learned handle weights "
                         "(cot Laplacian, fp64 Cholesky, lbs gradient) + locally_rigid_fn + mesh_laplacian_smoothing('cot'); "
                         + full_mode}
+        if dt_fused:
+            out["fused_render_loss"] = {
+                "value": round(world * N * a.steps / dt_fused, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * dt_fused / a.steps, 4),
+                "note": "same step, silhouette losses and the masked texture MSE fused into the raster kernels "
+                        "(NeuralRenderer.forward_silhouette_losses / forward_texture_mse: acfm_sil_loss_*, acfm_tex_mse_*); "
+                        "pix_to_face [N,H,W,20] still materialised"}
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",

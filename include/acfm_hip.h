@@ -220,6 +220,27 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
                       float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
                       int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
 
+/* ---- fused soft silhouette + silhouette losses (opt-in) --------------------------------
+ * acfm_sil_forward and acfm_mask_losses as ONE operator: the reference consumes the rendered mask at once
+ * (multiframe/main.py:644-645, 715-716: l1_loss / edt_loss of mask_pred; predictor.py:317-320), so the loss terms
+ * are summed in the raster kernel's epilogue (per-block partial sums, then summed per mesh in fixed order together
+ * with sum(gt): deterministic, no atomics) and the backward forms d loss / d mask on the fly from gt / edt and
+ * the per-mesh gradients -- the separate passes over the mask (acfm_mask_losses, acfm_mask_losses_backward)
+ * and the [N,H,H] grad_mask buffer disappear.  Same outputs as acfm_sil_forward plus
+ *   losses [N,4] = (mean|m - gt|, sum m gt, sum(m + gt - m gt), mean edt m)   (acfm_mask_losses' vector);
+ * gt / edt [ref_batch,H,H] (either may be NULL = zeros), prediction n <-> reference n % ref_batch.
+ * backward: grad_losses [N,4] -> grad_verts / grad_cams. */
+int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* gt,
+                          const float* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                          float blur_radius, float sigma, float offset_z, float* mask, int64_t* pix_to_face,
+                          uint64_t* kth, uint8_t* vis, float* losses, void* ws, size_t ws_bytes,
+                          const AcfmRasterTuning* tuning, void* stream);
+int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const float* mask,
+                           const uint64_t* kth, const float* gt, const float* edt, int ref_batch,
+                           const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
+                           float offset_z, float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
+                           int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
+
 /* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
  * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are
  * ALREADY projected by proj_fn; no y flip; view R=diag(-1,1,1), T=(0,0,2.732).
@@ -267,6 +288,23 @@ int acfm_tex_backward(const float* grad_imgs, const int32_t* texel_idx, int N, i
 int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, const void* ws, size_t ws_bytes,
                             float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
                             void* stream);
+
+/* ---- fused atlas-textured render + masked texture MSE (opt-in) ---------------------------
+ * acfm_tex_forward and acfm_tex_mse as ONE operator (multiframe/main.py:627-636 renders texture_pred and :655-662
+ * takes F.mse_loss(texture_pred * mask, imgs * mask).mean((1,2,3)) of it at once): the squared differences are summed
+ * in the raster kernel's epilogue (per-block partials, fixed-order sums: deterministic), and the atlas gradient is
+ * gathered per face straight from (imgs, ref_img, ref_mask, grad_loss) -- no [N,3,H,H] gradient image, no separate
+ * passes (acfm_tex_mse, acfm_tex_mse_backward).  Outputs of acfm_tex_forward plus loss [N];
+ * ref_img [ref_batch,3,H,H], ref_mask [ref_batch,H,H], prediction n <-> reference n % ref_batch.  R <= 8. */
+int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* atlas,
+                         const float* ref_img, const float* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
+                         float sigma, float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+                         int32_t* texel_idx, float* loss, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
+                         int atlas_batch, const AcfmRasterTuning* tuning, void* stream);
+int acfm_tex_mse_backward_faces(const float* imgs, const float* ref_img, const float* ref_mask, int ref_batch,
+                                const float* grad_loss, const int32_t* texel_idx, const void* ws, size_t ws_bytes,
+                                float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
+                                void* stream);
 
 /* ---- loss combination ------------------------------------------------------------------
  * replaces the elementwise tail of the trainer's total loss (multiframe/main.py:716-746, 749-765:

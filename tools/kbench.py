@@ -25,6 +25,7 @@ def main():
     p.add_argument("--subdiv", type=int, default=0, help="SubdivideMeshes passes (1: 642 v / 1280 f -> 2562 v / 5120 f, BASELINE config 5)")
     p.add_argument("--what", default="sil,tex,loss")
     p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
+    p.add_argument("--fused", type=int, default=0, help="1: the fused render+loss operator (acfm_sil_loss_*)")
     p.add_argument("--split", type=int, default=-3, help="block splitting: < 0 automatic, 0 never, 1 always")
     p.add_argument("--div", default="0,0,0", help="workgroups per group = entries / div: fwdK,fwd1,bwd (0 = default)")
     a = p.parse_args()
@@ -50,7 +51,12 @@ def main():
     tune.__enter__()
 
     def run():
-        if "sil" in a.what:
+        if "sil" in a.what and a.fused:
+            los, mask, p2f = ops.sil_render_losses(verts, faces, cams, H, gt, edt, k_out=(1 if a.kout == 1 else None))
+            proj = ops.project(verts, cams)[..., :2]
+            b = L.bds_loss(proj, bds, faces, p2f, reduce=False)
+            (los[:, 0] + los[:, 3] + 0.1 * b).mean().backward()
+        elif "sil" in a.what:
             mask, p2f = ops.sil_render(verts, faces, cams, H, k_out=(1 if a.kout == 1 else None))
             if "loss" in a.what:
                 l1, iou, e = L.fused_silhouette_losses(mask, gt, edt)
