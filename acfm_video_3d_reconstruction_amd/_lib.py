@@ -141,7 +141,7 @@ def require_gpu(*tensors):
 
 class RasterTuning(ctypes.Structure):
     """AcfmRasterTuning of include/acfm_hip.h (per call; results never depend on it)."""
-    _fields_ = [("split_mode", _i), ("grid_div", _i * 3)]
+    _fields_ = [("split_mode", _i), ("grid_div", _i * 3), ("flags", _i)]
 
 
 _TUNE = __import__("threading").local()
@@ -153,8 +153,9 @@ class raster_tuning:
     Tests use it to force the split / unsplit kernels and every grid divisor; the library itself keeps
     no tuning state."""
 
-    def __init__(self, split=-3, grid_div=(0, 0, 0)):
-        self.t = RasterTuning(int(split), (_i * 3)(*[int(d) for d in grid_div]))
+    def __init__(self, split=-3, grid_div=(0, 0, 0), deterministic=False):
+        """deterministic=True: the silhouette backward accumulates in fixed point (bit-reproducible run to run)."""
+        self.t = RasterTuning(int(split), (_i * 3)(*[int(d) for d in grid_div]), 1 if deterministic else 0)
 
     def __enter__(self):
         self.prev = getattr(_TUNE, "cur", None)

@@ -67,6 +67,7 @@ struct RasterWs {
   int4* vidx;      // [N,F] (i0,i1,i2,-)
   float4* mbox;    // [N,4] union of the face boxes of each of the 4 face slices of k_setup
   float* grad_ndc; // [N,V,2]
+  long long* grad_fix; // [N,V,2] the same in 2^-36 fixed point (deterministic backward)
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
   uint8_t* fvis;   // [N,F] 1 = the face is the nearest one at some pixel of the last texture render on this workspace
@@ -87,6 +88,7 @@ struct Tune {
   int split = -3;            // split heuristic: < 0 automatic (k_order: split while the longest block > (-split / 2) x mean work per wave slot), 0 never, 1 always
   int div[3] = {4, 2, 4};    // workgroups per XCD group = entries / div: [0] K-nearest forward, [1] nearest-face forward, [2] backward
                              // (measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us)
+  bool deterministic = false; // flags bit 0: fixed-point accumulation in the silhouette backward
 };
 static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
   if (!t) return true;
@@ -96,6 +98,8 @@ static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
     if (t->grid_div[i] < 0 || t->grid_div[i] > 64) return false;
     if (t->grid_div[i] > 0) out.div[i] = t->grid_div[i];   // 0 = keep the default
   }
+  if (t->flags & ~1) return false;
+  out.deterministic = (t->flags & 1) != 0;
   return true;
 }
 
@@ -118,6 +122,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
   w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * 4 * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
+  w.grad_fix = (long long*)(p + o); o += align256(sizeof(long long) * 2 * (size_t)N * V);
   const size_t tt = (size_t)((H + 7) / 8) * ((H + 7) / 8);  // 8x8-pixel blocks (RBLK)
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);

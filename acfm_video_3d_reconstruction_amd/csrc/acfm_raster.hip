@@ -117,6 +117,8 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
       if (vis) vis[(size_t)n * V + v] = 0;
       ws.grad_ndc[((size_t)n * V + v) * 2] = 0.f;
       ws.grad_ndc[((size_t)n * V + v) * 2 + 1] = 0.f;
+      ws.grad_fix[((size_t)n * V + v) * 2] = 0;
+      ws.grad_fix[((size_t)n * V + v) * 2 + 1] = 0;
     }
   }
   __syncthreads();
@@ -1657,10 +1659,27 @@ struct BwdGrad {
   const float* go;           // [N,4]
   int lrb;
 };
+// Deterministic accumulation (AcfmRasterTuning.flags bit 0): every row sum (a fixed DPP tree of values that are
+// themselves computed deterministically) is converted to 64-bit fixed point (2^-36 units) before it is added to
+// the candidate's LDS accumulator and, from there, to the vertex's accumulator in memory -- integer addition is
+// associative, so the result does not depend on the order in which blocks, rows and atomics happen to be
+// served: two runs are bit-identical.  Rounding each contribution to 2^-36 (1.5e-11) keeps it within 1e-6 of the
+// floating-point mode at the gradient scales of this problem (contributions up to ~1, sums up to ~1e3 of 2^27).
+constexpr float FIX_SCALE = 68719476736.0f;          // 2^36
+constexpr float FIX_INV = 1.0f / 68719476736.0f;
+__device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void acc_add(long long* p, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * FIX_SCALE));
+}
+__device__ __forceinline__ void acc_add_raw(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void acc_add_raw(long long* p, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+template <class AccT>
 __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const float* __restrict__ mask,
                                               const unsigned long long* __restrict__ kth,
                                               const BwdGrad& bg, int V, int F, int H, float blur,
-                                              float sigma, BwdList& L, fl_t* s_fl, float (*s_acc)[6]) {
+                                              float sigma, BwdList& L, fl_t* s_fl, AccT (*s_acc)[6]) {
   // d mask / d sd_k = -(1 - mask) * p_k / sigma   (robust form).  mask == 0
   // exactly means no face contributes (every p_k is 0 or the pixel is empty): no gradient.
   float coef = 0.f;
@@ -1691,9 +1710,11 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   const bool work = (coef != 0.0f);
   if (__ballot(work) == 0ull) return;
 
-  for (int i = t.tid; i < BWD_CAP * 6; i += RT) (&s_acc[0][0])[i] = 0.f;
+  for (int i = t.tid; i < BWD_CAP * 6; i += RT) (&s_acc[0][0])[i] = (AccT)0;
   wave_lds_sync();
-  float* gout = ws.grad_ndc + (size_t)t.n * V * 2;
+  AccT* gout;
+  if constexpr (sizeof(AccT) == 8) gout = reinterpret_cast<AccT*>(ws.grad_fix) + (size_t)t.n * V * 2;
+  else gout = reinterpret_cast<AccT*>(ws.grad_ndc) + (size_t)t.n * V * 2;
 
   bin_and_walk(ws, t, F, H, L, s_fl, 0.f, [&](int list_n) {
     walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
@@ -1736,33 +1757,35 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       g2x = row_sum_dpp(g2x); g2y = row_sum_dpp(g2y);
       // (a row without a face this iteration, or without members, sums to exact zeros)
       if ((t.lane & 15) == 15) {
-        float* acc = s_acc[cd.idx];   // two groups can hold the same face in one iteration: atomics
-        if (g0x != 0.f) atomicAdd(&acc[0], g0x);
-        if (g0y != 0.f) atomicAdd(&acc[1], g0y);
-        if (g1x != 0.f) atomicAdd(&acc[2], g1x);
-        if (g1y != 0.f) atomicAdd(&acc[3], g1y);
-        if (g2x != 0.f) atomicAdd(&acc[4], g2x);
-        if (g2y != 0.f) atomicAdd(&acc[5], g2y);
+        AccT* acc = s_acc[cd.idx];   // two groups can hold the same face in one iteration: atomics
+        if (g0x != 0.f) acc_add(&acc[0], g0x);
+        if (g0y != 0.f) acc_add(&acc[1], g0y);
+        if (g1x != 0.f) acc_add(&acc[2], g1x);
+        if (g1y != 0.f) acc_add(&acc[3], g1y);
+        if (g2x != 0.f) acc_add(&acc[4], g2x);
+        if (g2y != 0.f) acc_add(&acc[5], g2y);
       }
     });
     wave_lds_sync();
     for (int c = t.lane; c < list_n; c += RT) {
-      float* acc = s_acc[c];
-      const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
-      if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f) {
+      AccT* acc = s_acc[c];
+      const AccT z = (AccT)0;
+      const AccT a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
+      if (a0 != z || a1 != z || a2 != z || a3 != z || a4 != z || a5 != z) {
         const int4 vi = ws.vidx[(size_t)t.n * F + L.fid[c]];
-        if (a0 != 0.f) atomicAdd(&gout[2 * vi.x], a0);
-        if (a1 != 0.f) atomicAdd(&gout[2 * vi.x + 1], a1);
-        if (a2 != 0.f) atomicAdd(&gout[2 * vi.y], a2);
-        if (a3 != 0.f) atomicAdd(&gout[2 * vi.y + 1], a3);
-        if (a4 != 0.f) atomicAdd(&gout[2 * vi.z], a4);
-        if (a5 != 0.f) atomicAdd(&gout[2 * vi.z + 1], a5);
-        acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f; acc[4] = 0.f; acc[5] = 0.f;
+        if (a0 != z) acc_add_raw(&gout[2 * vi.x], a0);
+        if (a1 != z) acc_add_raw(&gout[2 * vi.x + 1], a1);
+        if (a2 != z) acc_add_raw(&gout[2 * vi.y], a2);
+        if (a3 != z) acc_add_raw(&gout[2 * vi.y + 1], a3);
+        if (a4 != z) acc_add_raw(&gout[2 * vi.z], a4);
+        if (a5 != z) acc_add_raw(&gout[2 * vi.z + 1], a5);
+        acc[0] = z; acc[1] = z; acc[2] = z; acc[3] = z; acc[4] = z; acc[5] = z;
       }
     }
   });
 }
 
+template <class AccT>
 __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
                                                  BwdGrad grad_mask, int N, int V,
@@ -1773,7 +1796,7 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
   // summed over the block's pixels; flushed (global float atomics on the face's three vertices)
   // and cleared after every walk.  (A [V][2] vertex accumulator per block merges more before
   // going to memory but costs 5 KB of LDS per wave at V = 642 and a clear + scan per block.)
-  __shared__ float s_acc[BWD_CAP][6];
+  __shared__ AccT s_acc[BWD_CAP][6];
   const Sched sc = make_sched(ws, N, H, true);
 #pragma unroll 1
   for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
@@ -1952,7 +1975,11 @@ __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ v
     const float* x = verts + ((size_t)n * V + v) * 3;
     const float X = x[0], Y = x[1], Z = x[2];
     float gx, gy, gz;
-    if (MODE == 1) {
+    if (MODE == 3) {            // NDC2 in 2^-36 fixed point (deterministic backward)
+      long long* g = reinterpret_cast<long long*>(gin) + ((size_t)n * V + v) * 2;
+      gx = -((float)g[0] * FIX_INV); gy = -((float)g[1] * FIX_INV); gz = 0.f;
+      g[0] = 0; g[1] = 0;
+    } else if (MODE == 1) {
       float* g = gin + ((size_t)n * V + v) * 2;
       gx = -g[0]; gy = -g[1]; gz = 0.f;
       g[0] = 0.f; g[1] = 0.f;   // the raster workspace's NDC-gradient scratch is left zeroed for the next backward
@@ -2458,15 +2485,22 @@ static int sil_backward_impl(const float* verts_world, const int64_t* faces, con
   const size_t lds = 0;
   {
     ProfScope ps(ACFM_PROF_SIL_BWD, st);
-    hipLaunchKernelGGL(k_sil_bwd, dim3(tile_grid(N, H, tn.div[2], ws.split_slots)), dim3(RT), lds, st, ws, mask,
-                       reinterpret_cast<const unsigned long long*>(kth), bg, N, V, F, H,
-                       blur_radius, sigma);
+    if (tn.deterministic)
+      hipLaunchKernelGGL(k_sil_bwd<long long>, dim3(tile_grid(N, H, tn.div[2], ws.split_slots)), dim3(RT), lds, st, ws,
+                         mask, reinterpret_cast<const unsigned long long*>(kth), bg, N, V, F, H, blur_radius, sigma);
+    else
+      hipLaunchKernelGGL(k_sil_bwd<float>, dim3(tile_grid(N, H, tn.div[2], ws.split_slots)), dim3(RT), lds, st, ws,
+                         mask, reinterpret_cast<const unsigned long long*>(kth), bg, N, V, F, H, blur_radius, sigma);
   }
   ACFM_CHECK_LAUNCH();
   if (grad_verts || grad_cams) {
     ProfScope ps(ACFM_PROF_PROJ_BWD, st);
-    hipLaunchKernelGGL((k_project_bwd<1>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
-                       ws.grad_ndc, V, grad_verts, grad_cams);
+    if (tn.deterministic)
+      hipLaunchKernelGGL((k_project_bwd<3>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
+                         reinterpret_cast<float*>(ws.grad_fix), V, grad_verts, grad_cams);
+    else
+      hipLaunchKernelGGL((k_project_bwd<1>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
+                         ws.grad_ndc, V, grad_verts, grad_cams);
     ACFM_CHECK_LAUNCH();
   }
   return ACFM_OK;

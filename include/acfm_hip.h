@@ -177,17 +177,22 @@ int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_hos
  * (face records, NDC verts, per-mesh boxes, tile schedule, gradient scratch). */
 size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
 
-/* Per-call launch tuning of the raster entry points (pure speed: results never depend on it).
+/* Per-call launch tuning of the raster entry points (pure speed: results never depend on it, `flags` apart).
  * NULL = the defaults.  There is no process-global tuning state in the library.
  *   split_mode: the heaviest 8x8 blocks of a small launch are rendered by four workgroups each;
  *               < 0 automatic (decided on the device from the cost histogram; default -3),
  *               0 never, 1 always (for every launch size);
  *   grid_div:   workgroups per XCD group = entries / div for [0] the K-nearest forward, [1] the
  *               nearest-face (K = 1) forward, [2] the silhouette backward; 0 = default (4, 2, 4).
+ *   flags:      bit 0 = deterministic silhouette backward: vertex gradients are accumulated in 64-bit fixed point
+ *               (2^-36 units) with integer atomics, so the sums do not depend on the order in which blocks are
+ *               served -- two runs are bit-identical, within 1e-6 of the default floating-point atomics (which are
+ *               reproducible only to ~1e-6 relative).  The one field that is not pure speed.
  * A backward call must pass the tuning of the forward whose workspace it takes over. */
 typedef struct AcfmRasterTuning {
   int split_mode;
   int grid_div[3];
+  int flags;
 } AcfmRasterTuning;
 
 /* ---- soft silhouette ---------------------------------------------------------------

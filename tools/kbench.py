@@ -25,6 +25,7 @@ def main():
     p.add_argument("--subdiv", type=int, default=0, help="SubdivideMeshes passes (1: 642 v / 1280 f -> 2562 v / 5120 f, BASELINE config 5)")
     p.add_argument("--what", default="sil,tex,loss")
     p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
+    p.add_argument("--det", type=int, default=0, help="1: deterministic (fixed-point) silhouette backward")
     p.add_argument("--fused", type=int, default=0, help="1: the fused render+loss operator (acfm_sil_loss_*)")
     p.add_argument("--split", type=int, default=-3, help="block splitting: < 0 automatic, 0 never, 1 always")
     p.add_argument("--div", default="0,0,0", help="workgroups per group = entries / div: fwdK,fwd1,bwd (0 = default)")
@@ -47,7 +48,7 @@ def main():
     bds = torch.cat([torch.rand(N, 800, 2, device=dev) * 2 - 1, torch.ones(N, 800, 1, device=dev)], -1)
     lib = _lib.lib()
     # --split / --div: per-call tuning of the raster entry points (AcfmRasterTuning), for experiments
-    tune = _lib.raster_tuning(split=a.split, grid_div=tuple(int(x) for x in a.div.split(",")))
+    tune = _lib.raster_tuning(split=a.split, grid_div=tuple(int(x) for x in a.div.split(",")), deterministic=bool(a.det))
     tune.__enter__()
 
     def run():
