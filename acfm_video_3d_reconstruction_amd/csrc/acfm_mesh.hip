@@ -34,6 +34,12 @@ __device__ __forceinline__ FaceCot face_cot(const float* __restrict__ v, long i0
 }
 
 // ---- a9: dense L = W - diag(rowsum W) of ONE mesh, L pre-zeroed -----------------------------
+// Two passes, bit-reproducible: (1) W_ij on the off-diagonal -- an interior edge receives exactly two
+// contributions and a + b = b + a, so the float atomics leave no trace of their order (a non-manifold edge with
+// three or more faces would); (2) the diagonal as -rowsum(W), summed in a fixed order per row, which is also how
+// the reference forms it (geom_utils.py:249-252: L = W - diag(W.sum(1))).  With the diagonal accumulated face by
+// face (up to a dozen atomics per vertex in arrival order) L, and with it P and every deformed vertex, changed
+// in the last bit from run to run -- enough to flip a K-truncation at a pixel now and then.
 __global__ void k_cot_laplacian(const float* __restrict__ verts, const int64_t* __restrict__ faces, int V,
                                 int F, float* __restrict__ L) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,11 +52,20 @@ __global__ void k_cot_laplacian(const float* __restrict__ verts, const int64_t* 
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const long i = e[k][0], j = e[k][1];
+    if (i == j) continue;   // (a face with a repeated vertex adds nothing to W - diag(rowsum W))
     atomicAdd(&L[(size_t)i * V + j], w[k]);
     atomicAdd(&L[(size_t)j * V + i], w[k]);
-    atomicAdd(&L[(size_t)i * V + i], -w[k]);
-    atomicAdd(&L[(size_t)j * V + j], -w[k]);
   }
+}
+// one wave per row: L_ii = -sum_{j != i} W_ij, lane-strided partial sums + a fixed shuffle tree
+__global__ __launch_bounds__(256) void k_cot_laplacian_diag(int V, float* __restrict__ L) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= V) return;
+  float* row = L + (size_t)i * V;
+  float s = 0.f;
+  for (int j = lane; j < V; j += 64) s += (j == i) ? 0.f : row[j];
+  s = wave_sum(s);
+  if (lane == 0) row[i] = -s;
 }
 
 // ---- a15: Laplacian smoothing -----------------------------------------------------------------
@@ -390,6 +405,7 @@ int acfm_cot_laplacian(const float* verts, const int64_t* faces, int V, int F, f
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(L, sizeof(float) * (size_t)V * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
   hipLaunchKernelGGL(k_cot_laplacian, dim3(nblk(F, 256)), dim3(256), 0, st, verts, faces, V, F, L);
+  hipLaunchKernelGGL(k_cot_laplacian_diag, dim3((V + 3) / 4), dim3(256), 0, st, V, L);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -78,6 +78,14 @@ class MultiframeStep(nn.Module):
         self.tex_renderer = NeuralRenderer(img_size)
         self.of_renderer = OF_NeuralRenderer(img_size)
 
+    def make_exchange(self, group=None, average=True):
+        """The frame-sharded step's one collective: pre-solve sums of the shared shape parameters (lbs,
+        mean shape) + any other learned shared tensor (vert2kp); per-frame embeddings stay on the owning rank.
+        average=True: ranks hold equal shards and per-rank losses are means over them."""
+        from .sharding import SharedShapeExchange
+        extra = [self.vert2kp] if isinstance(self.vert2kp, nn.Parameter) else []
+        return SharedShapeExchange(self.solver, extra_params=extra, group=group, average=average)
+
     def set_num_guesses(self, k):
         """train_utils.py:236-241: after the first epochs only the k most probable hypotheses of
         every frame are rendered (opts.drop_hypothesis)."""
@@ -157,7 +165,7 @@ class MultiframeStep(nn.Module):
 
     # ------------------------------------------------------------------ main.py:523-765
     def forward(self, batch, delta_v_res, textures=None, imgs=None, detach_camera=False, drop_deform=False,
-                predicted_camera=None):
+                predicted_camera=None, exchange=None):
         """delta_v_res [N,K_h,3]: handle offsets predicted by the (out-of-scope) encoder head;
         predicted_camera [N,7] (optional): output of its camera head, pulled towards the most
         probable hypothesis (main.py:753-762).  Returns (total_loss, dict of the reference's named terms)."""
@@ -181,8 +189,14 @@ class MultiframeStep(nn.Module):
             delta = deforms
         else:
             delta = delta_v_res
-        self.solver.refresh()       # lbs / mean shape moved in the last optimiser step: one factorisation
-        pred_v1 = self.solver(delta)                             # [N,V,3]
+        if exchange is not None:
+            # frame-sharded step (sharding.SharedShapeExchange over self.solver; `batch` holds this rank's clips,
+            # sharding.frame_shard): the local backward stops at the (P, mean) leaves, exchange.finish() after
+            # loss.backward() all-reduces the pre-solve sums and finishes d lbs identically on every rank
+            pred_v1 = exchange.apply(delta)
+        else:
+            self.solver.refresh()   # lbs / mean shape moved in the last optimiser step: one factorisation
+            pred_v1 = self.solver(delta)                         # [N,V,3]
         pred_v = pred_v1.repeat(G, 1, 1)
         faces = self.faces1[None].expand(G * N, -1, -1)
         terms = {}

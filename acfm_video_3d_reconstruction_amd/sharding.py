@@ -118,3 +118,95 @@ class SharedGradReducer:
             p.grad.copy_(flat[o:o + p.numel()].view_as(p))
             o += p.numel()
         return flat[o:o + n_extra].clone() if n_extra else None
+
+
+class SharedShapeExchange:
+    """The one exchange of a frame-sharded step whose shared parameters are the handle weights (lbs,
+    multiframe/nnutils/mesh_net.py:543-544) and the mean shape: SURVEY section 8e's packed buffer
+
+        [ G = sum_n g_n delta_n^T  (V x K_h)  |  sum_n g_n  (V x 3)  |  extra shared grads  |  loss scalars ]
+
+    i.e. the PRE-SOLVE sums.  pred_v_n = v + P delta_n with P = (L^T L + A^T A)^-1 A^T (deform.DeformSolver):
+    each rank back-propagates its own frames down to (dL/dP, dL/dv) -- exactly deform_apply's backward outputs
+    `grad_P = sum_n g_n delta_n^T` and `grad_mean = sum_n g_n` --, ONE all-reduce sums them over the ranks, and every
+    rank then finishes dL/dlbs = solve_backward(G) locally and identically (the factorisation is replicated, it is
+    cheap; reducing dlbs itself would be equivalent).  Per-frame parameters (handle offsets, cameras) never leave
+    their rank.
+
+        ex = SharedShapeExchange(solver, extra_params=[...])      # once
+        pred_v = ex.apply(delta_local)                             # forward on this rank's frames
+        loss_local.backward()                                      # local backward: stops at (P, mean) leaves
+        scalars = ex.finish(extra_scalars=loss_local.detach()[None])   # the collective + the solve backward
+        # now solver.lbs.grad / solver.mean_v.grad / extra_params' grads hold the full-batch gradients
+
+    average=True divides the reduced gradients by the world size (per-rank losses are means over equal shards)."""
+
+    def __init__(self, solver, extra_params=(), group=None, average=False, deterministic=False):
+        self.solver = solver
+        self.extra = [p for p in extra_params if p is not solver.lbs and p is not solver.mean_v]
+        self.group, self.average, self.deterministic = group, average, deterministic
+        self._flat = None
+        self._P = self._P_leaf = self._mean_leaf = None
+
+    def apply(self, delta):
+        """delta [n_local,K_h,3] -> pred_v [n_local,V,3]; one factorisation per call (lbs / mean shape may have moved)."""
+        s = self.solver
+        s.refresh()
+        self._P = s.solve_matrix()                                   # carries the autograd path to lbs when it is learned
+        self._P_leaf = self._P.detach().requires_grad_(True)
+        self._mean_leaf = s.mean_v.detach().requires_grad_(True)
+        if delta.is_cuda:
+            from . import ops
+            return ops.deform_apply(self._mean_leaf, self._P_leaf, delta)
+        return self._mean_leaf[None] + torch.matmul(self._P_leaf[None], delta)
+
+    def _buffer(self, n, device):
+        if self._flat is None or self._flat.numel() != n or self._flat.device != device:
+            self._flat = torch.zeros(n, dtype=torch.float32, device=device)
+        return self._flat
+
+    def finish(self, extra_scalars=None):
+        s = self.solver
+        gP = self._P_leaf.grad if self._P_leaf.grad is not None else torch.zeros_like(self._P_leaf)
+        gm = self._mean_leaf.grad if self._mean_leaf.grad is not None else torch.zeros_like(self._mean_leaf)
+        if s.mean_v.requires_grad and s.mean_v.grad is not None:       # the direct paths (priors on the template)
+            gm = gm + s.mean_v.grad
+        parts = [gP.reshape(-1), gm.reshape(-1)]
+        parts += [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.extra]
+        n_sc = 0 if extra_scalars is None else extra_scalars.numel()
+        if n_sc:
+            parts.append(extra_scalars.detach().reshape(-1).float())
+        n = sum(p.numel() for p in parts)
+        flat = self._buffer(n, gP.device)
+        torch.cat(parts, out=flat)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world > 1:
+            staged = flat.is_cuda and dist.get_backend(self.group) == "gloo"   # CPU rehearsal of the multi-rank path
+            buf = flat.cpu() if staged else flat
+            if self.deterministic:
+                gathered = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(gathered, buf, group=self.group)
+                buf.zero_()
+                for g in gathered:
+                    buf.add_(g)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if staged:
+                flat.copy_(buf)
+        n_grad = n - n_sc
+        if self.average and world > 1:
+            flat[:n_grad].div_(world)
+        o = gP.numel()
+        G = flat[:o].view_as(gP)
+        if s.lbs.requires_grad:
+            s.lbs.grad = None
+            self._P.backward(G)                                       # d lbs = solve_backward(G): identical on every rank
+        mean_g = flat[o:o + gm.numel()].view_as(gm)
+        o += gm.numel()
+        if s.mean_v.requires_grad:
+            s.mean_v.grad = mean_g.clone()
+        for p in self.extra:
+            p.grad = flat[o:o + p.numel()].view_as(p).clone()
+            o += p.numel()
+        self.bytes = 4 * n
+        return flat[n_grad:].clone() if n_sc else None

@@ -46,6 +46,10 @@ def parse():
     p.add_argument("--no-lean", action="store_true", help="skip the nearest-plane-only comparison run")
     p.add_argument("--eager", action="store_true",
                    help="launch every kernel of the step from Python instead of replaying one captured hipGraph")
+    p.add_argument("--learn-lbs", action="store_true",
+                   help="handle weights (lbs) and mean shape are learned shared parameters: every step re-factorises the "
+                        "deformation system and the ranks exchange the pre-solve sums [G = sum g delta^T | sum g | loss] "
+                        "(~50 KB, sharding.SharedShapeExchange) instead of the mean-shape gradient alone; eager launches")
     p.add_argument("--tex-stream", type=int, default=0,
                    help="texture branch on its own HIP stream (measured slower: 1.34 vs 1.26 ms/step)")
     return p.parse_args()
@@ -236,6 +240,44 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    # ---- --learn-lbs: the exchange the north star names (shared mean-shape AND handle-weight gradients)
+    lbs_info = None
+    if a.learn_lbs:
+        from acfm_video_3d_reconstruction_amd.sharding import SharedShapeExchange
+        lbs_q = torch.nn.Parameter(lbs_logits.clone())
+        mean_l = torch.nn.Parameter(mean_v.clone())
+        solver_l = DeformSolver(mean_l, faces[0], lbs_q)
+        ex = SharedShapeExchange(solver_l)
+
+        def lbs_step(ren=renderer):
+            pred_v = ex.apply(delta)                                       # one factorisation per step + deform apply
+            mask, p2f = ren(pred_v, faces, cams)
+            sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)
+            bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
+            tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)
+            tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
+            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
+            for p_ in (delta, cams, atlas):
+                p_.grad = None
+            total.backward()                                               # local: stops at the (P, mean) leaves
+            ex.finish(extra_scalars=total.detach().reshape(1))             # ONE all-reduce + the solve's backward
+            return total
+        for _ in range(a.warmup):
+            lbs_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            lbs_step()
+        fence()
+        dt_l = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_l], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_l = float(t.item())
+        lbs_info = dict(value=round(world * N * a.steps / dt_l, 2), unit="frames/s", ms_per_step=round(1e3 * dt_l / a.steps, 4),
+                        exchange_bytes=int(ex.bytes),
+                        note="lbs and mean shape learned: per-step factorisation + pre-solve exchange [G | sum g | loss], eager launches")
 
     dt = timed(renderer, a.warmup, a.steps)          # the drop-in API: pix_to_face [N,H,W,20] int64
     ms_step = 1e3 * dt / a.steps
@@ -452,6 +494,8 @@ def main():
                 "note": "same step, silhouette losses and the masked texture MSE fused into the raster kernels "
                         "(NeuralRenderer.forward_silhouette_losses / forward_texture_mse: acfm_sil_loss_*, acfm_tex_mse_*); "
                         "pix_to_face [N,H,W,20] still materialised"}
+        if lbs_info:
+            out["learn_lbs_step"] = lbs_info
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",

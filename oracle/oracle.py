@@ -613,12 +613,19 @@ def _f64(a):
 
 
 def multiframe_forward_terms(cam_emb, mirror_flag, transforms, lbs_logits, mean_v, faces, delta, masks,
-                             edts_barrier, boundaries, optical_flows=None, textures=None, imgs=None, **opts):
+                             edts_barrier, boundaries, optical_flows=None, textures=None, imgs=None,
+                             render_verts=None, render_cams=None, **opts):
     """ShapeTrainer.forward (main.py:523-765) between the network heads and the loss scalar, every named term.
     cam_emb [G,N,7] (camera embeddings of the N = B*T frames), mirror_flag [N], transforms [N,4],
     lbs_logits [V,Kh], mean_v [V,3], faces [F,3], delta [N,Kh,3] (= delta_v_res; drop_deform: zeros),
     masks [N,H,H], edts_barrier [N,1,H,H], boundaries [N,P,3], optical_flows [B,T,H,H,2],
-    textures [N,F,R,R,3], imgs [N,3,H,H].  Returns a dict of float64 tensors / numpy arrays."""
+    textures [N,F,R,R,3], imgs [N,3,H,H].  Returns a dict of float64 tensors / numpy arrays.
+    render_verts [N,V,3] / render_cams [G*N,7] (float32, optional): geometry handed to the rasteriser and to
+    everything downstream of it INSTEAD of this function's own float64 solve / camera chain (which are still
+    computed and returned as pred_v / cam_pred for comparison).  The render is discontinuous in its inputs -- a
+    depth swap at the K-th slot of one pixel moves a mask value by up to ~0.1 -- so a last-bit difference between
+    a float32 product solve and the float64 solve here can flip such an event; parity tests compare the solve and
+    the camera chain first (1e-5 / 1e-6) and then feed the product's float32 values to the oracle's downstream."""
     o = dict(DEFAULT_OPTS)
     o.update(opts)
     T = o["num_frames"]
@@ -636,6 +643,10 @@ def multiframe_forward_terms(cam_emb, mirror_flag, transforms, lbs_logits, mean_
     L = laplacian_cot(mean_v, faces_t)                                                      # :600-601
     pred_v1 = deform_solve(lbs_logits, mean_v, delta, L)                                    # :586-609
     out["pred_v"] = pred_v1
+    if render_verts is not None:
+        pred_v1 = _f64(render_verts)
+    if render_cams is not None:
+        cam = _f64(render_cams)
     pred_v = pred_v1.repeat(G, 1, 1)                                                        # :610
     pv32, cam32 = pred_v.float().numpy(), cam.float().numpy()
     faces_np = faces_t.numpy()
@@ -692,12 +703,14 @@ def multiframe_forward_terms(cam_emb, mirror_flag, transforms, lbs_logits, mean_
 
 
 def refine_iteration(lbs_logits, mean_v, faces, delta, cam_raw, masks, edts_barrier, boundaries, mask_loss_wt=1.0,
-                     boundaries_reg_wt=1.0, edt_reg_wt=0.1, bdt_reg_wt=0.1, optimize_camera=True):
+                     boundaries_reg_wt=1.0, edt_reg_wt=0.1, bdt_reg_wt=0.1, optimize_camera=True,
+                     render_verts=None, render_cams=None):
     """One iteration of the post-processing loop (predictor.py:301-345), loss and gradients:
     cam = (s, t, normalize(q)); pred_v = solve(delta); mask render; total = mask_wt * l1 + bds_wt *
     (bdt_reg_wt * edt_loss + edt_reg_wt * bdt_loss) (sic, :322).  Returns (total, d total / d delta,
     d total / d cam_raw, dict of the terms).  The raster / blend backward is the C oracle's, the rest
-    float64 autograd."""
+    float64 autograd.  render_verts / render_cams: float32 geometry for the rasteriser (see
+    multiframe_forward_terms); the differentiable chain stays this function's own float64 one."""
     lbs_logits, mean_v, masks, edts, bds = map(_f64, (lbs_logits, mean_v, masks, edts_barrier, boundaries))
     faces_t = torch.as_tensor(np.asarray(faces)).long()
     delta = _f64(delta).clone().requires_grad_(True)
@@ -708,6 +721,10 @@ def refine_iteration(lbs_logits, mean_v, faces, delta, cam_raw, masks, edts_barr
     L = laplacian_cot(mean_v, faces_t)
     pred_v = deform_solve(lbs_logits, mean_v, delta, L)
     pv32, cam32, faces_np = pred_v.detach().float().numpy(), cam.detach().float().numpy(), faces_t.numpy()
+    if render_verts is not None:
+        pv32 = np.ascontiguousarray(render_verts, dtype=np.float32)
+    if render_cams is not None:
+        cam32 = np.ascontiguousarray(render_cams, dtype=np.float32)
     mask_pred, p2f = sil_render(pv32, faces_np, cam32, H)
     mp = torch.from_numpy(mask_pred).double().requires_grad_(True)
     mask_loss = l1_loss(mp, masks)
