@@ -58,7 +58,8 @@ SIGNATURES = {
     "acfm_tex_backward_faces": (_i, [_vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_tex_mse_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _sz, _i, _f, _i, _vp, _vp]),
-    "acfm_tex_mse_backward_faces": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_tex_mse_backward_faces": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _f, _i, _i, _i, _i, _i, _i, _vp, _vp,
+                                         _vp]),
     "acfm_combine_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_combine_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -154,7 +155,9 @@ class raster_tuning:
     no tuning state."""
 
     def __init__(self, split=-3, grid_div=(0, 0, 0), deterministic=False):
-        """deterministic=True: the silhouette backward accumulates in fixed point (bit-reproducible run to run)."""
+        """deterministic=True: the silhouette backward accumulates in fixed point (bit-reproducible run to run).
+        (Bit 1 of the flags, half storage, is not set here: it changes buffer types, so the ops that support it take
+        storage="f16" and set it themselves -- with_f16() below.)"""
         self.t = RasterTuning(int(split), (_i * 3)(*[int(d) for d in grid_div]), 1 if deterministic else 0)
 
     def __enter__(self):
@@ -174,6 +177,13 @@ def tuning():
 
 def tuning_ptr(t):
     return ctypes.byref(t) if t is not None else None
+
+
+def with_f16(t, on):
+    """The tuning in effect with flags bit 1 (ACFM_STORE_F16) set or cleared: a fresh structure."""
+    if t is None:
+        return RasterTuning(-3, (_i * 3)(0, 0, 0), 2) if on else None
+    return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~2) | (2 if on else 0))
 
 
 _CONSTS = {}

@@ -89,6 +89,7 @@ struct Tune {
   int div[3] = {4, 2, 4};    // workgroups per XCD group = entries / div: [0] K-nearest forward, [1] nearest-face forward, [2] backward
                              // (measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us)
   bool deterministic = false; // flags bit 0: fixed-point accumulation in the silhouette backward
+  bool f16 = false;           // flags bit 1: half storage of masks / images / atlases, int32 nearest-face plane
 };
 static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
   if (!t) return true;
@@ -98,8 +99,9 @@ static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
     if (t->grid_div[i] < 0 || t->grid_div[i] > 64) return false;
     if (t->grid_div[i] > 0) out.div[i] = t->grid_div[i];   // 0 = keep the default
   }
-  if (t->flags & ~1) return false;
+  if (t->flags & ~3) return false;
   out.deterministic = (t->flags & 1) != 0;
+  out.f16 = (t->flags & 2) != 0;
   return true;
 }
 

@@ -859,19 +859,42 @@ __device__ __forceinline__ unsigned long long make_key(float pz, int fid) {
 }
 
 // ------------------------------------------------------------------------------- forward
+// Storage type of images and masks: float, or IEEE half with ACFM_STORE_F16 (AcfmRasterTuning.flags bit 1, BASELINE
+// config 5 "fp16 render with fp32 loss accumulate").  Only what is STORED changes: every accept / reject decision,
+// depth, blend factor and loss sum is computed in fp32 exactly as in the fp32 build, so face ids are identical.
+typedef _Float16 half_t;
+__device__ __forceinline__ float ld_real(const void* p, size_t i, int h16) {
+  return h16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_real(void* p, size_t i, float v, int h16) {
+  if (h16) reinterpret_cast<half_t*>(p)[i] = (half_t)v;
+  else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float4 ld4_real(const void* p, size_t i4, int h16) {   // elements 4 i4 .. 4 i4 + 3 (aligned)
+  if (!h16) return reinterpret_cast<const float4*>(p)[i4];
+  typedef half_t h4 __attribute__((ext_vector_type(4)));
+  const h4 v = reinterpret_cast<const h4*>(p)[i4];
+  return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void st_face(void* p, size_t i, long long id, int h16) {   // nearest-face plane
+  if (h16) reinterpret_cast<int32_t*>(p)[i] = (int32_t)id;
+  else reinterpret_cast<int64_t*>(p)[i] = (int64_t)id;
+}
+
 struct FwdOut {
   unsigned long long* dbg;   // diagnostic build only: per-block (t_start, t_end, hw_id) stamps
-  float* mask;               // soft: [N,H,H]
-  int64_t* p2f;              // [N,H,H,kout]
+  int h16;                   // ACFM_STORE_F16: mask / imgs / sil / atlas / references are IEEE half, p2f is an int32 [N,H,H] plane
+  void* mask;                // soft: [N,H,H] (real_t = float, or half with h16)
+  void* p2f;                 // [N,H,H,kout] int64; h16: [N,H,H] int32 (kout = 1)
   int kout;                  // soft: K (all kept faces) or 1 (nearest face only)
   unsigned long long* kth;   // soft, optional: [N,H,H] largest kept key if K faces kept, else ~0
   uint8_t* vis;              // optional: [N,V] vertices of every nearest face
   int V;
   // texture branch (TEX)
   const float* vrgb;         // optional [N,V,3]: per-vertex colours instead of an atlas (viz)
-  const float* atlas;        // [N,F,R,R,3]
-  float* imgs;               // [N,3,H,H]
-  float* sil;                // [N,H,H]
+  const void* atlas;         // [N,F,R,R,3] real_t
+  void* imgs;                // [N,3,H,H] real_t
+  void* sil;                 // [N,H,H] real_t
   int32_t* tidx;             // [N,H,H]
   int R;
   float gamma;
@@ -881,14 +904,14 @@ struct FwdOut {
                              // from the kernarg segment with a scalar load where a computed value would be spilled
   // fused render + silhouette losses (acfm_sil_loss_forward): the block's partial sums of the loss terms leave
   // with the mask; lpart == null: plain render
-  const float* lgt;          // [lrb,H,H] ground-truth masks (may be null)
-  const float* ledt;         // [lrb,H,H] distance transforms (may be null)
+  const void* lgt;           // [lrb,H,H] real_t ground-truth masks (may be null)
+  const void* ledt;          // [lrb,H,H] real_t distance transforms (may be null)
   int lrb;                   // references: mesh n is compared with reference n % lrb
   float4* lpart;             // [N,blocks^2,4] (ws.lpart)
   // fused texture render + masked MSE (acfm_tex_mse_forward): lpart[..].x takes the block's sum of
   // (tex m - img m)^2 - (img m)^2 over its covered pixels (elsewhere tex = 0 and the difference vanishes)
-  const float* timg;         // [lrb,3,H,H] reference images
-  const float* tmask;        // [lrb,H,H] reference masks
+  const void* timg;          // [lrb,3,H,H] real_t reference images
+  const void* tmask;         // [lrb,H,H] real_t reference masks
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -1239,19 +1262,19 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
       out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (!valid) return;
-    out.p2f[pix] = (int64_t)-1;
+    st_face(out.p2f, pix, -1, out.h16);
     if (TEX) {
       const size_t HW = (size_t)H * H;
-      float* img = out.imgs + (size_t)n * 3 * HW + (size_t)yi * H + xi;
-      img[0] = 0.f; img[HW] = 0.f; img[2 * HW] = 0.f;
-      out.sil[pix] = 0.f;
+      const size_t io = (size_t)n * 3 * HW + (size_t)yi * H + xi;
+      st_real(out.imgs, io, 0.f, out.h16); st_real(out.imgs, io + HW, 0.f, out.h16); st_real(out.imgs, io + 2 * HW, 0.f, out.h16);
+      st_real(out.sil, pix, 0.f, out.h16);
       out.tidx[pix] = -1;
     }
   } else {
     if (valid) {
-      out.mask[pix] = 0.0f;
+      st_real(out.mask, pix, 0.0f, out.h16);
       if (out.kth) out.kth[pix] = KEY_NONE;
-      if (out.kout == 1) out.p2f[pix] = (long long)-1;
+      if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
     }
     if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
       const int tiles = (H + RBLK - 1) / RBLK;
@@ -1266,7 +1289,7 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
       const int c = i * 64 + lane;             // piece index: 8 rows x (8 pixels x CH pieces)
       const int r = c / (8 * CH), off = c % (8 * CH);
       if (by + r < H && bx + off / CH < H)
-        reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = v;
+        reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off] = v;
     }
   }
 }
@@ -1343,16 +1366,16 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       test_face_dist(t.xf, t.yf, ws.rec[o].a, ws.rec[o].b, 0.0f, true, h);
       bestsd = h.sd;
     }
-    out.p2f[t.pix] = hit ? fbase + f : (int64_t)-1;
+    st_face(out.p2f, t.pix, hit ? fbase + f : (int64_t)-1, out.h16);
     if (out.vis && hit) mark_visible(ws, out, n, F, f);
     if (TEX) {
       // TexturesAtlas.sample_textures + ambient-only Phong + softmax_rgb_blend, K = 1
       // (oracle_atlas_shade is the line-by-line spec)
       const size_t HW = (size_t)H * H;
-      float* img = out.imgs + (size_t)n * 3 * HW + (size_t)t.yi * H + t.xi;
+      const size_t io = (size_t)n * 3 * HW + (size_t)t.yi * H + t.xi;
       if (!hit) {
-        img[0] = 0.f; img[HW] = 0.f; img[2 * HW] = 0.f;
-        out.sil[t.pix] = 0.f;
+        st_real(out.imgs, io, 0.f, out.h16); st_real(out.imgs, io + HW, 0.f, out.h16); st_real(out.imgs, io + 2 * HW, 0.f, out.h16);
+        st_real(out.sil, t.pix, 0.f, out.h16);
         out.tidx[t.pix] = -1;
       } else {
         const int R = out.R;
@@ -1381,20 +1404,21 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
           cg = bestb0 * c0[1] + bestb1 * c1[1] + b2 * c2[1];
           cb = bestb0 * c0[2] + bestb1 * c1[2] + b2 * c2[2];
         } else {
-          const float* tx3 = out.atlas + ti * 3;
-          cr = tx3[0]; cg = tx3[1]; cb = tx3[2];
+          cr = ld_real(out.atlas, ti * 3, out.h16); cg = ld_real(out.atlas, ti * 3 + 1, out.h16);
+          cb = ld_real(out.atlas, ti * 3 + 2, out.h16);
         }
         const float vr = (wnum * cr + delta * 0.0f) / den, vg = (wnum * cg + delta * 0.0f) / den,
                     vb = (wnum * cb + delta * 0.0f) / den;
-        img[0] = vr; img[HW] = vg; img[2 * HW] = vb;
-        out.sil[t.pix] = 1.0f - (1.0f - prob);
+        st_real(out.imgs, io, vr, out.h16); st_real(out.imgs, io + HW, vg, out.h16); st_real(out.imgs, io + 2 * HW, vb, out.h16);
+        st_real(out.sil, t.pix, 1.0f - (1.0f - prob), out.h16);
         out.tidx[t.pix] = (int32_t)ti;
         ws.fvis[(size_t)n * F + f] = 1;   // the atlas gradient (k_tex_bwd_faces) visits only faces that were seen
         if (out.lpart) {
           const size_t pp = (size_t)t.yi * H + t.xi, rn = (size_t)(n % out.lrb);
-          const float mk = out.tmask[rn * HW + pp];
-          const float* ri = out.timg + rn * 3 * HW + pp;
-          const float b0 = ri[0] * mk, b1 = ri[HW] * mk, b2 = ri[2 * HW] * mk;
+          const float mk = ld_real(out.tmask, rn * HW + pp, out.h16);
+          const size_t ro = rn * 3 * HW + pp;
+          const float b0 = ld_real(out.timg, ro, out.h16) * mk, b1 = ld_real(out.timg, ro + HW, out.h16) * mk,
+                      b2 = ld_real(out.timg, ro + 2 * HW, out.h16) * mk;
           const float d0 = vr * mk - b0, d1 = vg * mk - b1, d2 = vb * mk - b2;
           tacc = (d0 * d0 - b0 * b0) + (d1 * d1 - b1 * b1) + (d2 * d2 - b2 * b2);
         }
@@ -1501,21 +1525,21 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     float lmask = 0.f, lg = 0.f, le = 0.f;
     if (out.lpart && out_valid) {
       const size_t rp = t.pix - (size_t)n * H * H + (size_t)(n % out.lrb) * H * H;
-      if (out.lgt) lg = out.lgt[rp];
-      if (out.ledt) le = out.ledt[rp];
+      if (out.lgt) lg = ld_real(out.lgt, rp, out.h16);
+      if (out.ledt) le = ld_real(out.ledt, rp, out.h16);
     }
     if (out_valid) {
       float alpha = 1.0f;  // sigmoid_alpha_blend over the kept faces in ascending depth; empty slots hold 1
 #pragma unroll
       for (int k = 0; k < K; ++k) alpha = alpha * q[k];
-      out.mask[t.pix] = 1.0f - alpha;
+      st_real(out.mask, t.pix, 1.0f - alpha, out.h16);
       if (out.kth) out.kth[t.pix] = key[K - 1];  // ~0 unless K faces are kept
       lmask = 1.0f - alpha;
       if (out.vis && key[0] != KEY_NONE) mark_visible(ws, out, n, F, (int)(key[0] & 0xffffffffu));
       // lean output: only the nearest-face plane, the one slot any caller of the reference
       // reads (loss_utils.py:214, 431); the other K-1 ids stay in registers
       if (out.kout == 1)
-        out.p2f[t.pix] = (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1;
+        st_face(out.p2f, t.pix, (key[0] != KEY_NONE) ? fbase + (long long)(key[0] & 0xffffffffu) : (long long)-1, out.h16);
     }
     // Fused silhouette losses: with m = 0 outside the blocks that have work, sum|m - g| = sum g + sum(|m - g| - g),
     // sum(m + g - m g) = sum g + sum(m - m g); the finish kernels add sum g.  One 16-byte store per block (and
@@ -1560,10 +1584,10 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         const int c = i * 64 + t.lane;             // piece index: 8 rows x (8 pixels x CH pieces)
         const int r = c / (8 * CH), off = c % (8 * CH);
         if (by + r < H && bx + off / CH < H)
-          reinterpret_cast<ll2*>(out.p2f + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
+          reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
       }
     } else if (out_valid) {
-      ll2* o2 = reinterpret_cast<ll2*>(out.p2f + t.pix * K);
+      ll2* o2 = reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + t.pix * K);
 #pragma unroll
       for (int k2 = 0; k2 < CH; ++k2) {
         ll2 v;
@@ -1653,11 +1677,12 @@ using BwdList = CandListT<BWD_CAP>;
 // formed on the fly from the references and the per-mesh gradients of the four loss terms -- k_mask_losses_bwd's
 // expression, operation for operation: go0 sign(m - g) / HW + go1 g + go2 (1 - g) + go3 e / HW.
 struct BwdGrad {
-  const float* grad_mask;    // [N,H,H], or null: fused
-  const float* lgt;          // [lrb,H,H] (may be null)
-  const float* ledt;         // [lrb,H,H] (may be null)
+  const float* grad_mask;    // [N,H,H] (always float), or null: fused
+  const void* lgt;           // [lrb,H,H] real_t (may be null)
+  const void* ledt;          // [lrb,H,H] real_t (may be null)
   const float* go;           // [N,4]
   int lrb;
+  int h16;                   // mask / lgt / ledt are half
 };
 // Deterministic accumulation (AcfmRasterTuning.flags bit 0): every row sum (a fixed DPP tree of values that are
 // themselves computed deterministically) is converted to 64-bit fixed point (2^-36 units) before it is added to
@@ -1676,7 +1701,7 @@ __device__ __forceinline__ void acc_add_raw(long long* p, long long v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
 template <class AccT>
-__device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const float* __restrict__ mask,
+__device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const void* __restrict__ mask,
                                               const unsigned long long* __restrict__ kth,
                                               const BwdGrad& bg, int V, int F, int H, float blur,
                                               float sigma, BwdList& L, fl_t* s_fl, AccT (*s_acc)[6]) {
@@ -1687,7 +1712,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   const float sig_scale = sigmoid_scale(sigma);
   if (t.empty) return;  // the forward wrote mask = 0 here
   if (t.valid) {
-    const float m = mask[t.pix];
+    const float m = ld_real(mask, t.pix, bg.h16);
     if (m != 0.0f) {
       float gm;
       if (bg.grad_mask) {
@@ -1695,7 +1720,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       } else {
         const size_t HW = (size_t)H * H;
         const size_t rp = t.pix - (size_t)t.n * HW + (size_t)(t.n % bg.lrb) * HW;
-        const float g = bg.lgt ? bg.lgt[rp] : 0.f, e = bg.ledt ? bg.ledt[rp] : 0.f;
+        const float g = bg.lgt ? ld_real(bg.lgt, rp, bg.h16) : 0.f, e = bg.ledt ? ld_real(bg.ledt, rp, bg.h16) : 0.f;
         const float inv = 1.0f / (float)HW;
         const float* go = bg.go + 4 * (size_t)t.n;
         const float g0 = go[0] * inv, g1 = go[1], g2 = go[2], g3 = go[3] * inv;
@@ -1786,7 +1811,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
 }
 
 template <class AccT>
-__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __restrict__ mask,
+__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const void* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
                                                  BwdGrad grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {
@@ -1812,8 +1837,8 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const float* __rest
 // in the first (one workgroup per mesh was latency-bound: 45 us for 64 meshes); every sum is formed in a fixed
 // order (thread-strided partial sums, a fixed tree, then the chunks in order): deterministic, no atomics.
 constexpr int FIN_CHUNKS = 8;
-__global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restrict__ lpart, const float* __restrict__ gt,
-                                                           int tt, int HW, int RB, float* __restrict__ part2) {
+__global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restrict__ lpart, const void* __restrict__ gt,
+                                                           int tt, int HW, int RB, int h16, float* __restrict__ part2) {
   __shared__ float s_red[TPB][5];
   const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, gs = 0.f;
@@ -1824,7 +1849,7 @@ __global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restri
     a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
   }
   if (gt) {
-    const float* g = gt + (size_t)(n % RB) * HW;
+    const size_t go = (size_t)(n % RB) * HW;
     if ((HW & 3) == 0) {
       const int q = HW / 4, q_lo = (int)((long long)q * ch / FIN_CHUNKS), q_hi = (int)((long long)q * (ch + 1) / FIN_CHUNKS);
       constexpr int U = 8;                       // loads of a round in flight together
@@ -1833,14 +1858,14 @@ __global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int i = i0 + u * TPB;
-          v[u] = i < q_hi ? reinterpret_cast<const float4*>(g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[u] = i < q_hi ? ld4_real(gt, go / 4 + i, h16) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) gs += (v[u].x + v[u].y) + (v[u].z + v[u].w);
       }
     } else {
       const int g_lo = (int)((long long)HW * ch / FIN_CHUNKS), g_hi = (int)((long long)HW * (ch + 1) / FIN_CHUNKS);
-      for (int i = g_lo + tid; i < g_hi; i += TPB) gs += g[i];
+      for (int i = g_lo + tid; i < g_hi; i += TPB) gs += ld_real(gt, go + i, h16);
     }
   }
   s_red[tid][0] = a0; s_red[tid][1] = a1; s_red[tid][2] = a2; s_red[tid][3] = a3; s_red[tid][4] = gs;
@@ -1869,9 +1894,9 @@ __global__ void k_sil_loss_finish2(const float* __restrict__ part2, int N, int H
 
 // Fused texture render + masked MSE, finish: out[n] = (sum over the mesh's blocks of their partial
 // + sum_c sum_px (img_c m)^2) / (3 HW) -- the second term is what an uncovered pixel (tex = 0) contributes.
-__global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restrict__ lpart, const float* __restrict__ timg,
-                                                           const float* __restrict__ tmask, int tt, int HW, int RB,
-                                                           float* __restrict__ part2) {
+__global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restrict__ lpart, const void* __restrict__ timg,
+                                                           const void* __restrict__ tmask, int tt, int HW, int RB,
+                                                           int h16, float* __restrict__ part2) {
   __shared__ float s_red[TPB];
   const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
   float acc = 0.f;
@@ -1879,8 +1904,7 @@ __global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restri
   const int t_lo = (int)((long long)tt * ch / FIN_CHUNKS), t_hi = (int)((long long)tt * (ch + 1) / FIN_CHUNKS);
   for (int i = t_lo + tid; i < t_hi; i += TPB) acc += p[4 * (size_t)i].x;
   const size_t rn = (size_t)(n % RB);
-  const float* m = tmask + rn * HW;
-  const float* im = timg + rn * 3 * HW;
+  const size_t mo = rn * HW, io = rn * 3 * HW;
   if ((HW & 3) == 0) {
     const int q = HW / 4, q_lo = (int)((long long)q * ch / FIN_CHUNKS), q_hi = (int)((long long)q * (ch + 1) / FIN_CHUNKS);
     constexpr int U = 4;
@@ -1891,10 +1915,10 @@ __global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restri
         const int i = i0 + u * TPB;
         const bool in = i < q_hi;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        mk[u] = in ? reinterpret_cast<const float4*>(m)[i] : z;
-        c0[u] = in ? reinterpret_cast<const float4*>(im)[i] : z;
-        c1[u] = in ? reinterpret_cast<const float4*>(im + HW)[i] : z;
-        c2[u] = in ? reinterpret_cast<const float4*>(im + 2 * (size_t)HW)[i] : z;
+        mk[u] = in ? ld4_real(tmask, mo / 4 + i, h16) : z;
+        c0[u] = in ? ld4_real(timg, io / 4 + i, h16) : z;
+        c1[u] = in ? ld4_real(timg, (io + HW) / 4 + i, h16) : z;
+        c2[u] = in ? ld4_real(timg, (io + 2 * (size_t)HW) / 4 + i, h16) : z;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1908,8 +1932,9 @@ __global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restri
   } else {
     const int g_lo = (int)((long long)HW * ch / FIN_CHUNKS), g_hi = (int)((long long)HW * (ch + 1) / FIN_CHUNKS);
     for (int i = g_lo + tid; i < g_hi; i += TPB) {
-      const float mk = m[i];
-      const float b0 = im[i] * mk, b1 = im[HW + i] * mk, b2 = im[2 * (size_t)HW + i] * mk;
+      const float mk = ld_real(tmask, mo + i, h16);
+      const float b0 = ld_real(timg, io + i, h16) * mk, b1 = ld_real(timg, io + HW + i, h16) * mk,
+                  b2 = ld_real(timg, io + 2 * (size_t)HW + i, h16) * mk;
       acc += b0 * b0 + b1 * b1 + b2 * b2;
     }
   }
@@ -2058,31 +2083,36 @@ constexpr int TEXG_U = 8;        // big boxes: 64 U pixels per round, all their 
 // on the fly from the rendered image, the reference image and mask and the per-mesh gradient of the loss --
 // k_tex_mse_bwd's expression: w (tex m - img m) m with w = go[n] 2 / (3 HW).
 struct TexGrad {
-  const float* grad_imgs;    // [N,3,H,H], or null: fused
-  const float* imgs;         // [N,3,H,H] the forward's output
-  const float* timg;         // [rb,3,H,H]
-  const float* tmask;        // [rb,H,H]
+  const float* grad_imgs;    // [N,3,H,H] (always float), or null: fused
+  const void* imgs;          // [N,3,H,H] real_t, the forward's output
+  const void* timg;          // [rb,3,H,H] real_t
+  const void* tmask;         // [rb,H,H] real_t
   const float* go;           // [N]
   int rb;
+  int h16;
 };
 struct TexGradN {            // the same for one mesh n
-  const float *g, *ri, *rm;
+  const float* g;
+  const void *im, *ri, *rm;
+  size_t io, ro, mo;
   float w;
   size_t HW;
+  int h16;
   __device__ __forceinline__ void load(size_t p, float& r, float& gg, float& b) const {
-    if (!rm) { r = g[p]; gg = g[HW + p]; b = g[2 * HW + p]; return; }
-    const float mk = rm[p];
-    r = w * (g[p] * mk - ri[p] * mk) * mk;
-    gg = w * (g[HW + p] * mk - ri[HW + p] * mk) * mk;
-    b = w * (g[2 * HW + p] * mk - ri[2 * HW + p] * mk) * mk;
+    if (g) { r = g[p]; gg = g[HW + p]; b = g[2 * HW + p]; return; }
+    const float mk = ld_real(rm, mo + p, h16);
+    r = w * (ld_real(im, io + p, h16) * mk - ld_real(ri, ro + p, h16) * mk) * mk;
+    gg = w * (ld_real(im, io + HW + p, h16) * mk - ld_real(ri, ro + HW + p, h16) * mk) * mk;
+    b = w * (ld_real(im, io + 2 * HW + p, h16) * mk - ld_real(ri, ro + 2 * HW + p, h16) * mk) * mk;
   }
 };
 __device__ __forceinline__ TexGradN tex_grad_of(const TexGrad& tg, int n, size_t HW) {
-  TexGradN t;
+  TexGradN t = {};
   t.HW = HW;
-  if (tg.grad_imgs) { t.g = tg.grad_imgs + (size_t)n * 3 * HW; t.ri = nullptr; t.rm = nullptr; t.w = 0.f; return t; }
+  if (tg.grad_imgs) { t.g = tg.grad_imgs + (size_t)n * 3 * HW; return t; }
   const size_t rn = (size_t)(n % tg.rb);
-  t.g = tg.imgs + (size_t)n * 3 * HW; t.ri = tg.timg + rn * 3 * HW; t.rm = tg.tmask + rn * HW;
+  t.im = tg.imgs; t.ri = tg.timg; t.rm = tg.tmask; t.h16 = tg.h16;
+  t.io = (size_t)n * 3 * HW; t.ro = rn * 3 * HW; t.mo = rn * HW;
   t.w = tg.go[n] * 2.0f / (3.0f * (float)HW);
   return t;
 }
@@ -2401,9 +2431,9 @@ int acfm_project_xy_backward(const float* verts, const float* cams, const float*
 
 static int sil_forward_impl(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
                             int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
-                            float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                            void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
                             size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream, bool fused,
-                            const float* gt, const float* edt, int ref_batch, float* losses) {
+                            const void* gt, const void* edt, int ref_batch, float* losses) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (fused && (!losses || ref_batch <= 0 || N % ref_batch != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
@@ -2411,6 +2441,7 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
     return ACFM_E_BADARG;
   Tune tn;
   if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  if (tn.f16 && k_out != 1) return ACFM_E_BADARG;      // half storage goes with the int32 nearest-face plane
   const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -2418,6 +2449,7 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   if (rc) return rc;
   FwdOut out = {};
   out.dbg = g_dbg;
+  out.h16 = tn.f16 ? 1 : 0;
   out.mask = mask;
   out.p2f = pix_to_face;
   out.kout = k_out;
@@ -2440,7 +2472,7 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   const int tiles = (H + RBLK - 1) / RBLK;
   ProfScope ps(ACFM_PROF_MASK_LOSS, st);
   hipLaunchKernelGGL(k_sil_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, gt, tiles * tiles, H * H,
-                     ref_batch, ws.lpart2);
+                     ref_batch, out.h16, ws.lpart2);
   hipLaunchKernelGGL(k_sil_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, losses);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -2448,15 +2480,15 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
 
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
                      int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
-                     float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                     void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
                      size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream) {
   return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
                           pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr);
 }
 
-int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* gt,
-                          const float* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
-                          float blur_radius, float sigma, float offset_z, float* mask, int64_t* pix_to_face,
+int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* gt,
+                          const void* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                          float blur_radius, float sigma, float offset_z, void* mask, void* pix_to_face,
                           uint64_t* kth, uint8_t* vis, float* losses, void* wsp, size_t ws_bytes,
                           const AcfmRasterTuning* tuning, void* stream) {
   return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
@@ -2464,7 +2496,7 @@ int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const 
 }
 
 static int sil_backward_impl(const float* verts_world, const int64_t* faces, const float* cams,
-                             const float* mask, const uint64_t* kth, const BwdGrad& bg, int N, int V,
+                             const void* mask, const uint64_t* kth, BwdGrad bg, int N, int V,
                              int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
                              float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
                              const AcfmRasterTuning* tuning, void* stream) {
@@ -2473,6 +2505,7 @@ static int sil_backward_impl(const float* verts_world, const int64_t* faces, con
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
   Tune tn;
   if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  bg.h16 = tn.f16 ? 1 : 0;
   const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);   // (same tuning as the forward whose workspace this is)
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -2507,7 +2540,7 @@ static int sil_backward_impl(const float* verts_world, const int64_t* faces, con
 }
 
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
-                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                      const void* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
                       float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
                       const AcfmRasterTuning* tuning, void* stream) {
@@ -2519,8 +2552,8 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
                            grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream);
 }
 
-int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const float* mask,
-                           const uint64_t* kth, const float* gt, const float* edt, int ref_batch,
+int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const void* mask,
+                           const uint64_t* kth, const void* gt, const void* edt, int ref_batch,
                            const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
                            float offset_z, float* grad_verts, float* grad_cams, void* wsp, size_t ws_bytes,
                            int ws_from_forward, const AcfmRasterTuning* tuning, void* stream) {
@@ -2536,7 +2569,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
                      const AcfmRasterTuning* tuning, void* stream) {
   if (!verts_proj || !faces || !pix_to_face || !wsp || bad_dims(N, V, F, H)) return ACFM_E_BADARG;
   Tune tn;
-  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  if (!tune_from(tuning, tn) || tn.f16) return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -2555,11 +2588,11 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
 }
 
 static int tex_forward_impl(const float* verts_world, const int64_t* faces, const float* cams,
-                            const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
-                            float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
+                            const void* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
+                            float offset_z, void* imgs, void* sil, void* pix_to_face, int32_t* texel_idx,
                             void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
-                            const AcfmRasterTuning* tuning, void* stream, const float* ref_img,
-                            const float* ref_mask, int ref_batch, float* loss) {
+                            const AcfmRasterTuning* tuning, void* stream, const void* ref_img,
+                            const void* ref_mask, int ref_batch, float* loss) {
   if (!verts_world || !faces || !cams || !atlas || !imgs || !sil || !pix_to_face || !texel_idx || !wsp)
     return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || R <= 0 || R > 256 || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
@@ -2580,6 +2613,7 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.p2f = pix_to_face;
   out.atlas = atlas; out.imgs = imgs; out.sil = sil; out.tidx = texel_idx; out.R = R; out.gamma = gamma;
   out.atlas_n = atlas_batch;
+  out.h16 = tn.f16 ? 1 : 0;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   out.lrb = 1;
   if (loss) {
@@ -2596,7 +2630,7 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
     const int tiles = (H + RBLK - 1) / RBLK;
     ProfScope ps(ACFM_PROF_TEX_MSE, st);
     hipLaunchKernelGGL(k_tex_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, ref_img, ref_mask,
-                       tiles * tiles, H * H, ref_batch, ws.lpart2);
+                       tiles * tiles, H * H, ref_batch, out.h16, ws.lpart2);
     hipLaunchKernelGGL(k_tex_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, loss);
     ACFM_CHECK_LAUNCH();
   }
@@ -2604,8 +2638,8 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
 }
 
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
-                     const float* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
-                     float offset_z, float* imgs, float* sil, int64_t* pix_to_face, int32_t* texel_idx,
+                     const void* atlas, int N, int V, int F, int H, int R, float sigma, float gamma,
+                     float offset_z, void* imgs, void* sil, void* pix_to_face, int32_t* texel_idx,
                      void* wsp, size_t ws_bytes, int ws_ready, float ws_blur, int atlas_batch,
                      const AcfmRasterTuning* tuning, void* stream) {
   return tex_forward_impl(verts_world, faces, cams, atlas, N, V, F, H, R, sigma, gamma, offset_z, imgs, sil,
@@ -2613,9 +2647,9 @@ int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float
                           nullptr, nullptr, 1, nullptr);
 }
 
-int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* atlas,
-                         const float* ref_img, const float* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
-                         float sigma, float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* atlas,
+                         const void* ref_img, const void* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
+                         float sigma, float gamma, float offset_z, void* imgs, void* sil, void* pix_to_face,
                          int32_t* texel_idx, float* loss, void* wsp, size_t ws_bytes, int ws_ready, float ws_blur,
                          int atlas_batch, const AcfmRasterTuning* tuning, void* stream) {
   if (!loss) return ACFM_E_BADARG;
@@ -2632,7 +2666,7 @@ int acfm_vertex_color_forward(const float* verts_world, const int64_t* faces, co
   if (!verts_world || !faces || !cams || !verts_rgb || !imgs || !sil || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || !(gamma > 0.f)) return ACFM_E_BADARG;
   Tune tn;
-  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
+  if (!tune_from(tuning, tn) || tn.f16) return ACFM_E_BADARG;
   const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes + sizeof(int32_t) * (size_t)N * H * H > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -2699,12 +2733,15 @@ int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, co
   return tex_backward_faces_impl(tg, texel_idx, wsp, ws_bytes, ws_blur, N, V, F, H, R, atlas_batch, grad_atlas, stream);
 }
 
-int acfm_tex_mse_backward_faces(const float* imgs, const float* ref_img, const float* ref_mask, int ref_batch,
+int acfm_tex_mse_backward_faces(const void* imgs, const void* ref_img, const void* ref_mask, int ref_batch,
                                 const float* grad_loss, const int32_t* texel_idx, const void* wsp, size_t ws_bytes,
                                 float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
-                                void* stream) {
+                                const AcfmRasterTuning* tuning, void* stream) {
   if (!imgs || !ref_img || !ref_mask || !grad_loss || ref_batch <= 0 || N <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;
+  Tune tn;
+  if (!tune_from(tuning, tn)) return ACFM_E_BADARG;
   TexGrad tg = {};
+  tg.h16 = tn.f16 ? 1 : 0;
   tg.imgs = imgs; tg.timg = ref_img; tg.tmask = ref_mask; tg.go = grad_loss; tg.rb = ref_batch;
   return tex_backward_faces_impl(tg, texel_idx, wsp, ws_bytes, ws_blur, N, V, F, H, R, atlas_batch, grad_atlas, stream);
 }

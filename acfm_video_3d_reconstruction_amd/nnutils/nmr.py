@@ -20,14 +20,18 @@ class NeuralRenderer(torch.nn.Module):
     it in nn.DataParallel, main.py:183-193); honours the input tensors' device and the
     current HIP stream."""
 
-    def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4, pix_to_face_slots=None):
+    def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4, pix_to_face_slots=None, storage="f32"):
         """pix_to_face_slots: None -> pix_to_face [N,H,W,faces_per_pixel] exactly like the
         reference; 1 -> only the nearest-face plane [N,H,W,1] is written to HBM (all the
         reference's callers read: `pix_to_face[..., 0]` loss_utils.py:214, `[..., :1]` :431).
         The mask always blends the faces_per_pixel nearest faces."""
         super().__init__()
         self.img_size = img_size
-        self.pix_to_face_slots = pix_to_face_slots
+        # storage="f16" (BASELINE config 5, "fp16 render with fp32 loss accumulate"): rendered masks / images and the
+        # atlas are held in float16 and pix_to_face is the int32 nearest-face plane [N,H,W,1]; every decision of the
+        # rasteriser and every loss sum stays float32 (ids identical to the float32 renderer)
+        self.storage = storage
+        self.pix_to_face_slots = 1 if storage == "f16" else pix_to_face_slots
         self.faces_per_pixel = faces_per_pixel          # nmr.py:158
         self.sigma = sigma                              # nmr.py:153
         self.gamma = gamma
@@ -66,7 +70,7 @@ class NeuralRenderer(torch.nn.Module):
             masks, pix_to_face = ops.sil_render(vertices, faces, cams, self.img_size,
                                                 K=self.faces_per_pixel, blur=self.blur_radius,
                                                 sigma=self.sigma, offset_z=self.offset_z,
-                                                k_out=self.pix_to_face_slots)
+                                                k_out=self.pix_to_face_slots, storage=self.storage)
             return masks, pix_to_face
         self.mask_only = False
         if not atlas:  # nmr.py:177-179: Textures(verts_rgb), visualisation only (no gradients)
@@ -76,7 +80,7 @@ class NeuralRenderer(torch.nn.Module):
                                            self.img_size, sigma=1e-4, gamma=1e-4, offset_z=self.offset_z)
         imgs, sil, pix_to_face = ops.tex_render(vertices, faces, cams, textures.to(vertices.device),
                                                 self.img_size, sigma=1e-4, gamma=1e-4,
-                                                offset_z=self.offset_z)
+                                                offset_z=self.offset_z, storage=self.storage)
         return imgs, sil, pix_to_face
 
 
@@ -88,7 +92,7 @@ class NeuralRenderer(torch.nn.Module):
         out, masks, pix_to_face = ops.sil_render_losses(vertices, faces, cams, self.img_size, mask_gt, edt,
                                                         K=self.faces_per_pixel, blur=self.blur_radius,
                                                         sigma=self.sigma, offset_z=self.offset_z,
-                                                        k_out=self.pix_to_face_slots)
+                                                        k_out=self.pix_to_face_slots, storage=self.storage)
         if raw:
             return out, masks, pix_to_face
         return (out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]), masks, pix_to_face
@@ -99,7 +103,7 @@ class NeuralRenderer(torch.nn.Module):
         F.mse_loss(texture_pred * masks, imgs * masks, reduction='none').mean((1, 2, 3)), as one call.
         -> (mse [N], texture_pred (no gradient), sil, pix_to_face)."""
         return ops.tex_render_mse(vertices, faces, cams, textures.to(vertices.device), imgs, masks, self.img_size,
-                                  sigma=1e-4, gamma=1e-4, offset_z=self.offset_z)
+                                  sigma=1e-4, gamma=1e-4, offset_z=self.offset_z, storage=self.storage)
 
 
 class OF_NeuralRenderer(torch.nn.Module):

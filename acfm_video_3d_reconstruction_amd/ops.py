@@ -18,6 +18,17 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _real(t, f16):
+    """Storage tensor of the raster ops: float32, or float16 with storage="f16" (ACFM_STORE_F16)."""
+    return t.detach().to(torch.float16 if f16 else torch.float32).contiguous()
+
+
+def _is_f16(storage):
+    if storage not in ("f32", "f16"):
+        raise ValueError("storage must be 'f32' or 'f16', got %r" % (storage,))
+    return storage == "f16"
+
+
 _FACES = {}   # (storage ptr, offset, strides, version, shape, N) -> (source kept alive, contiguous int64 [N,F,3])
 
 
@@ -414,18 +425,21 @@ def correlation(f1, f2, max_displacement):
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, faces, cams, img_size, K, blur, sigma, offset_z, k_out):
+    def forward(ctx, verts, faces, cams, img_size, K, blur, sigma, offset_z, k_out, f16=False):
         _lib.require_gpu(verts, faces, cams)
         v, c = _f32c(verts), _f32c(cams)
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
-        mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
-        p2f = torch.empty((N, H, H, k_out), dtype=torch.int64, device=v.device)
+        if f16 and k_out != 1:
+            raise ValueError("storage='f16' writes the int32 nearest-face plane only (k_out = 1)")
+        mask = torch.empty((N, H, H), dtype=torch.float16 if f16 else torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, k_out), dtype=torch.int32 if f16 else torch.int64, device=v.device)
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
-        tp, tune = _lib.tuning()
+        tune = _lib.with_f16(_lib.tuning()[1], True) if f16 else _lib.tuning()[1]
+        tp = _lib.tuning_ptr(tune)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
@@ -447,7 +461,7 @@ class _SilRender(torch.autograd.Function):
         N, V, _ = v.shape
         F = f.shape[1]
         if gmask is None:
-            return None, None, None, None, None, None, None, None, None
+            return (None,) * 10
         g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
@@ -457,18 +471,19 @@ class _SilRender(torch.autograd.Function):
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
                 V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_backward")
-        return gv, None, gc, None, None, None, None, None, None
+        return (gv, None, gc) + (None,) * 7
 
 
 def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0,
-               k_out=None):
+               k_out=None, storage="f32"):
     """Soft silhouette: -> (mask [N,H,H] f32, pix_to_face [N,H,H,k_out] i64), k_out = K (default,
     what PyTorch3D returns) or 1 (nearest-face plane only; K faces are still blended).
     The visible-vertex bitmap the raster kernel produces on the side (vertices of every
     nearest face, = what bds_loss / optical_flow_loss derive from pix_to_face[..., 0]) rides
     along on the pix_to_face tensor object as `._acfm_vis`."""
+    f16 = _is_f16(storage)   # "f16": mask [N,H,H] float16, pix_to_face [N,H,H,1] int32 (BASELINE config 5); fp32 arithmetic
     mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z,
-                                      K if k_out is None else int(k_out))
+                                      (1 if f16 else K) if k_out is None else int(k_out), f16)
     p2f._acfm_vis = vis
     return mask, p2f
 
@@ -477,27 +492,30 @@ class _SilRenderLosses(torch.autograd.Function):
     """acfm_sil_loss_forward / _backward: soft silhouette render + the [N,4] silhouette-loss vector as one operator."""
 
     @staticmethod
-    def forward(ctx, verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z, k_out):
+    def forward(ctx, verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z, k_out, f16=False):
         _lib.require_gpu(verts, faces, cams, gt, edt)
         v, c = _f32c(verts), _f32c(cams)
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
-        g = _f32c(gt).reshape(-1, H, H) if gt is not None else None
-        e = _f32c(edt).reshape(-1, H, H) if edt is not None else None
+        if f16 and k_out != 1:
+            raise ValueError("storage='f16' writes the int32 nearest-face plane only (k_out = 1)")
+        g = _real(gt, f16).reshape(-1, H, H) if gt is not None else None
+        e = _real(edt, f16).reshape(-1, H, H) if edt is not None else None
         RB = N
         for r in (g, e):
             if r is not None:
                 RB = _ref_batch(N, r, "sil_render_losses")
         if g is not None and e is not None and g.shape[0] != e.shape[0]:
             raise ValueError("sil_render_losses: gt and edt must have the same batch")
-        mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
-        p2f = torch.empty((N, H, H, k_out), dtype=torch.int64, device=v.device)
+        mask = torch.empty((N, H, H), dtype=torch.float16 if f16 else torch.float32, device=v.device)
+        p2f = torch.empty((N, H, H, k_out), dtype=torch.int32 if f16 else torch.int64, device=v.device)
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         losses = torch.empty((N, 4), dtype=torch.float32, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
-        tp, tune = _lib.tuning()
+        tune = _lib.with_f16(_lib.tuning()[1], True) if f16 else _lib.tuning()[1]
+        tp = _lib.tuning_ptr(tune)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_loss_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(g), _lib.ptr(e), RB, N, V, F, H, K, int(k_out),
@@ -519,7 +537,7 @@ class _SilRenderLosses(torch.autograd.Function):
         H, blur, sigma, offset_z, RB = ctx.cfg
         N, V, _ = v.shape
         F = f.shape[1]
-        none = (None,) * 11
+        none = (None,) * 12
         if glosses is None:
             return none
         go = _f32c(glosses)
@@ -535,14 +553,15 @@ class _SilRenderLosses(torch.autograd.Function):
 
 
 def sil_render_losses(verts, faces, cams, img_size, gt=None, edt=None, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA,
-                      offset_z=0.0, k_out=None):
+                      offset_z=0.0, k_out=None, storage="f32"):
     """Soft-silhouette render and its silhouette losses as ONE operator (opt-in; the drop-in pair is
     sil_render + mask_losses): -> (losses [N,4] = (mean|m-gt|, sum m*gt, sum(m+gt-m*gt), mean edt*m), mask [N,H,H],
     pix_to_face [N,H,H,k_out]).  Gradients flow from `losses` to verts / cams; `mask` is returned for inspection and
     carries none (use sil_render when the mask itself feeds further differentiable code).  gt / edt: [N,...] or
     [N/G,...] shared by the G hypotheses of a frame."""
+    f16 = _is_f16(storage)   # "f16": mask and the references are held in float16, the loss sums stay float32
     losses, mask, p2f, vis = _SilRenderLosses.apply(verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z,
-                                                    K if k_out is None else int(k_out))
+                                                    (1 if f16 else K) if k_out is None else int(k_out), f16)
     p2f._acfm_vis = vis
     return losses, mask, p2f
 
@@ -574,9 +593,9 @@ TEX_BWD_GATHER = True
 
 class _TexRender(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, verts, faces, cams, atlas, img_size, sigma, gamma, offset_z):
+    def forward(ctx, verts, faces, cams, atlas, img_size, sigma, gamma, offset_z, f16=False):
         _lib.require_gpu(verts, faces, cams, atlas)
-        v, c, a = _f32c(verts), _f32c(cams), _f32c(atlas)
+        v, c, a = _f32c(verts), _f32c(cams), _real(atlas, f16)   # (a float32 atlas is cast per call: hold it in half to spare that)
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
@@ -585,9 +604,10 @@ class _TexRender(torch.autograd.Function):
             raise ValueError("atlas must be [N,F,R,R,3] (or [N/G,F,R,R,3], shared by G hypotheses), got %s for "
                              "N=%d F=%d" % (tuple(a.shape), N, F))
         R = a.shape[2]
-        imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
-        sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
-        p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+        rdt = torch.float16 if f16 else torch.float32
+        imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
+        sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
+        p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
         tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         shared = _shared_setup(v, c, f, H, offset_z)
         if shared is not None:      # the workspace (and the tuning it was carved with) of the silhouette render
@@ -595,6 +615,7 @@ class _TexRender(torch.autograd.Function):
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
+        tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
@@ -603,6 +624,7 @@ class _TexRender(torch.autograd.Function):
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R, NA, V)
+        ctx.adt = atlas.dtype
         ctx.ws = (ws, nb, float(ws_blur))   # face boxes: the gather form of the atlas gradient walks them
         ctx.mark_non_differentiable(sil, p2f)
         ctx.set_materialize_grads(False)
@@ -628,25 +650,27 @@ class _TexRender(torch.autograd.Function):
                                "acfm_tex_backward")
         # geometry / camera: integer texel lookup and K=1 blending send (numerically) no
         # gradient -- |d rgb / d dist| <= 1e-6 |texel| from the delta=1e-10 term.
-        return None, None, None, ga, None, None, None, None
+        if ga is not None and ctx.adt != torch.float32:
+            ga = ga.to(ctx.adt)
+        return None, None, None, ga, None, None, None, None, None
 
 
-def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
+def tex_render(verts, faces, cams, atlas, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0, storage="f32"):
     """Atlas-textured hard render: -> (imgs [N,3,H,H], sil [N,H,H], pix_to_face [N,H,H,1]).
     atlas [N,F,R,R,3], or [N/G,F,R,R,3] when G hypotheses of every frame share the frame's
     texture (mesh n samples atlas n % (N/G); equivalent to atlas.repeat(G,1,1,1,1) without the
     copies, gradients of the G renders summed)."""
-    return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z)
+    return _TexRender.apply(verts, faces, cams, atlas, img_size, sigma, gamma, offset_z, _is_f16(storage))
 
 
 class _TexRenderMSE(torch.autograd.Function):
     """acfm_tex_mse_forward / acfm_tex_mse_backward_faces: atlas render + masked MSE against reference images as one op."""
 
     @staticmethod
-    def forward(ctx, verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z):
+    def forward(ctx, verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z, f16=False):
         _lib.require_gpu(verts, faces, cams, atlas, ref_img, ref_mask)
-        v, c, a = _f32c(verts), _f32c(cams), _f32c(atlas)
-        ri, rm = _f32c(ref_img), _f32c(ref_mask)
+        v, c, a = _f32c(verts), _f32c(cams), _real(atlas, f16)
+        ri, rm = _real(ref_img, f16), _real(ref_mask, f16)
         N, V, _ = v.shape
         f = expand_faces(faces, N)
         F, H = f.shape[1], int(img_size)
@@ -660,9 +684,10 @@ class _TexRenderMSE(torch.autograd.Function):
         if ri.shape[1:] != (3, H, H) or rm.reshape(-1, H, H).shape[0] != RB:
             raise ValueError("ref_img [N or N/G,3,H,H] and ref_mask [same batch,H,H]")
         rm = rm.reshape(RB, H, H)
-        imgs = torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device)
-        sil = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
-        p2f = torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device)
+        rdt = torch.float16 if f16 else torch.float32
+        imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
+        sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
+        p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
         tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         loss = torch.empty((N,), dtype=torch.float32, device=v.device)
         shared = _shared_setup(v, c, f, H, offset_z)
@@ -671,6 +696,7 @@ class _TexRenderMSE(torch.autograd.Function):
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
+        tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_mse_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), _lib.ptr(ri), _lib.ptr(rm), RB, N, V, F, H, R,
@@ -679,6 +705,7 @@ class _TexRenderMSE(torch.autograd.Function):
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_mse_forward")
         ctx.save_for_backward(tidx, imgs, ri, rm)
         ctx.cfg = (N, F, H, R, NA, V, RB)
+        ctx.adt, ctx.tune = atlas.dtype, tune
         ctx.ws = (ws, nb, float(ws_blur))
         ctx.mark_non_differentiable(imgs, sil, p2f)
         ctx.set_materialize_grads(False)
@@ -696,15 +723,20 @@ class _TexRenderMSE(torch.autograd.Function):
             with torch.cuda.device(g.device):
                 _lib.check(_lib.lib().acfm_tex_mse_backward_faces(
                     _lib.ptr(imgs), _lib.ptr(ri), _lib.ptr(rm), RB, _lib.ptr(g), _lib.ptr(tidx), _lib.ptr(ws), nb,
-                    ws_blur, N, V, F, H, R, NA, _lib.ptr(ga), _lib.cur_stream(g.device)), "acfm_tex_mse_backward_faces")
-        return (None, None, None, ga) + (None,) * 6
+                    ws_blur, N, V, F, H, R, NA, _lib.ptr(ga), _lib.tuning_ptr(ctx.tune), _lib.cur_stream(g.device)),
+                    "acfm_tex_mse_backward_faces")
+            if ctx.adt != torch.float32:
+                ga = ga.to(ctx.adt)
+        return (None, None, None, ga) + (None,) * 7
 
 
-def tex_render_mse(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):
+def tex_render_mse(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0,
+                   storage="f32"):
     """Atlas-textured render and its masked MSE against reference images as ONE operator (opt-in; the drop-in pair is
     tex_render + tex_mse): -> (loss [N] = mean over (3,H,W) of (tex*mask - img*mask)^2, imgs [N,3,H,H] (no gradient),
     sil, pix_to_face).  Gradient flows from `loss` to the atlas.  ref_img / ref_mask: [N,...] or [N/G,...]."""
-    return _TexRenderMSE.apply(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z)
+    return _TexRenderMSE.apply(verts, faces, cams, atlas, ref_img, ref_mask, img_size, sigma, gamma, offset_z,
+                               _is_f16(storage))
 
 
 def vertex_color_render(verts, faces, cams, verts_rgb, img_size, sigma=1e-4, gamma=1e-4, offset_z=0.0):

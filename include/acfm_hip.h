@@ -40,6 +40,8 @@ extern "C" {
 
 #define ACFM_MAX_K 32      /* faces_per_pixel upper bound */
 #define ACFM_MAX_FACES 65535 /* faces per mesh (16-bit local ids in the per-pixel lists) */
+#define ACFM_DETERMINISTIC 1 /* AcfmRasterTuning.flags */
+#define ACFM_STORE_F16 2
 
 /* library / device info ------------------------------------------------------------- */
 int acfm_version(void);              /* 1000*major + minor */
@@ -187,7 +189,15 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
  *   flags:      bit 0 = deterministic silhouette backward: vertex gradients are accumulated in 64-bit fixed point
  *               (2^-36 units) with integer atomics, so the sums do not depend on the order in which blocks are
  *               served -- two runs are bit-identical, within 1e-6 of the default floating-point atomics (which are
- *               reproducible only to ~1e-6 relative).  The one field that is not pure speed.
+ *               reproducible only to ~1e-6 relative);
+ *               bit 1 = ACFM_STORE_F16 (BASELINE config 5, "fp16 render with fp32 loss accumulate"): the buffers
+ *               declared `void*` [real] below hold IEEE half instead of float (rendered masks, images, silhouettes,
+ *               atlases and the reference masks / distance transforms / images of the fused operators), and
+ *               pix_to_face is an int32 [N,H,H] nearest-face plane (k_out must be 1).  Only storage changes: every
+ *               accept / reject decision, depth, blend and loss sum stays fp32, so face ids are identical to the
+ *               fp32 build and losses differ by the half rounding of what is stored (IoU drift < 1e-4).
+ *               Gradients (grad_mask, grad_losses, grad_atlas, grad_verts, grad_cams) are always float.
+ *               These two bits are the only fields that are not pure speed.
  * A backward call must pass the tuning of the forward whose workspace it takes over. */
 typedef struct AcfmRasterTuning {
   int split_mode;
@@ -211,8 +221,9 @@ typedef struct AcfmRasterTuning {
  * K in {2,4,8,10,20,32}. */
 int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float* cams, int N,
                      int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
-                     float offset_z, float* mask, int64_t* pix_to_face, uint64_t* kth, uint8_t* vis,
-                     void* ws, size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream);
+                     float offset_z, void* mask /* [real] */, void* pix_to_face /* int64, or the int32 plane */,
+                     uint64_t* kth, uint8_t* vis, void* ws, size_t ws_bytes, const AcfmRasterTuning* tuning,
+                     void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
@@ -220,7 +231,7 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
  * ws_from_forward != 0: `ws` is the untouched workspace of the matching acfm_sil_forward call
  * (same verts/faces/cams/H/blur) and the face setup is not repeated; 0: it is rebuilt here. */
 int acfm_sil_backward(const float* verts_world, const int64_t* faces, const float* cams,
-                      const float* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                      const void* mask /* [real] */, const uint64_t* kth, const float* grad_mask, int N, int V,
                       int F, int H, float blur_radius, float sigma, float offset_z,
                       float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
                       int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
@@ -235,13 +246,13 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
  *   losses [N,4] = (mean|m - gt|, sum m gt, sum(m + gt - m gt), mean edt m)   (acfm_mask_losses' vector);
  * gt / edt [ref_batch,H,H] (either may be NULL = zeros), prediction n <-> reference n % ref_batch.
  * backward: grad_losses [N,4] -> grad_verts / grad_cams. */
-int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* gt,
-                          const float* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
-                          float blur_radius, float sigma, float offset_z, float* mask, int64_t* pix_to_face,
+int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* gt /* [real] */,
+                          const void* edt /* [real] */, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                          float blur_radius, float sigma, float offset_z, void* mask /* [real] */, void* pix_to_face,
                           uint64_t* kth, uint8_t* vis, float* losses, void* ws, size_t ws_bytes,
                           const AcfmRasterTuning* tuning, void* stream);
-int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const float* mask,
-                           const uint64_t* kth, const float* gt, const float* edt, int ref_batch,
+int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const void* mask,
+                           const uint64_t* kth, const void* gt, const void* edt, int ref_batch,
                            const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
                            float offset_z, float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
                            int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
@@ -270,8 +281,8 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
  * texture, textures.repeat(G, ...) at main.py:627-636: atlas_batch = N / G spares the copies, and
  * the backward accumulates the G renders straight into the one gradient). */
 int acfm_tex_forward(const float* verts_world, const int64_t* faces, const float* cams,
-                     const float* atlas, int N, int V, int F, int H, int R, float sigma,
-                     float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+                     const void* atlas /* [real] */, int N, int V, int F, int H, int R, float sigma,
+                     float gamma, float offset_z, void* imgs /* [real] */, void* sil /* [real] */, void* pix_to_face,
                      int32_t* texel_idx, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
                      int atlas_batch, const AcfmRasterTuning* tuning, void* stream);
 /* NeuralRenderer.forward with atlas=False (multiframe/nnutils/nmr.py:177-179, used by
@@ -301,15 +312,15 @@ int acfm_tex_backward_faces(const float* grad_imgs, const int32_t* texel_idx, co
  * gathered per face straight from (imgs, ref_img, ref_mask, grad_loss) -- no [N,3,H,H] gradient image, no separate
  * passes (acfm_tex_mse, acfm_tex_mse_backward).  Outputs of acfm_tex_forward plus loss [N];
  * ref_img [ref_batch,3,H,H], ref_mask [ref_batch,H,H], prediction n <-> reference n % ref_batch.  R <= 8. */
-int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const float* atlas,
-                         const float* ref_img, const float* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
-                         float sigma, float gamma, float offset_z, float* imgs, float* sil, int64_t* pix_to_face,
+int acfm_tex_mse_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* atlas,
+                         const void* ref_img, const void* ref_mask, int ref_batch, int N, int V, int F, int H, int R,
+                         float sigma, float gamma, float offset_z, void* imgs, void* sil, void* pix_to_face,
                          int32_t* texel_idx, float* loss, void* ws, size_t ws_bytes, int ws_ready, float ws_blur,
                          int atlas_batch, const AcfmRasterTuning* tuning, void* stream);
-int acfm_tex_mse_backward_faces(const float* imgs, const float* ref_img, const float* ref_mask, int ref_batch,
+int acfm_tex_mse_backward_faces(const void* imgs, const void* ref_img, const void* ref_mask, int ref_batch,
                                 const float* grad_loss, const int32_t* texel_idx, const void* ws, size_t ws_bytes,
                                 float ws_blur, int N, int V, int F, int H, int R, int atlas_batch, float* grad_atlas,
-                                void* stream);
+                                const AcfmRasterTuning* tuning, void* stream);
 
 /* ---- loss combination ------------------------------------------------------------------
  * replaces the elementwise tail of the trainer's total loss (multiframe/main.py:716-746, 749-765:
