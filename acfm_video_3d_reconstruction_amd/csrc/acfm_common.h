@@ -76,7 +76,7 @@ struct RasterWs {
   unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every 32x32-pixel coarse tile (words = ceil(F/64) u64)
   float4* lpart;   // [N,blocks^2,4] fused render+loss: per 8x8 block (x 4 split roles) partial sums of the silhouette
                    // loss terms, written by the raster kernel, summed in fixed order by k_sil_loss_finish
-  float* lpart2;   // [N,8,5] second-stage partial sums of the same
+  float* lpart2;   // [N,64,5] second-stage partial sums of the same
   size_t bytes;
 };
 
@@ -133,7 +133,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
   const size_t ct = (size_t)((H + 31) / 32) * ((H + 31) / 32), words = ((size_t)F + 63) / 64;
   w.cmask = (unsigned*)(p + o); o += align256(sizeof(unsigned) * 2 * (size_t)N * ct * words);
   w.lpart = (float4*)(p + o);   o += align256(sizeof(float4) * 4 * (size_t)N * tt);
-  w.lpart2 = (float*)(p + o);   o += align256(sizeof(float) * 5 * 8 * (size_t)N);
+  w.lpart2 = (float*)(p + o);   o += align256(sizeof(float) * 5 * 64 * (size_t)N);
   w.bytes = o;
   return w;
 }

@@ -1836,11 +1836,16 @@ __global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const void* __restr
 // sum(m + g - m g), mean e m), the [N,4] vector of k_mask_losses.  Two short launches, FIN_CHUNKS workgroups per mesh
 // in the first (one workgroup per mesh was latency-bound: 45 us for 64 meshes); every sum is formed in a fixed
 // order (thread-strided partial sums, a fixed tree, then the chunks in order): deterministic, no atomics.
-constexpr int FIN_CHUNKS = 8;
+constexpr int FIN_MAX_CHUNKS = 64;   // (sizes ws.lpart2)
+static int fin_chunks(int N) {       // enough workgroups to fill the chip at any batch size: ~2048 in all
+  int c = 8;
+  while (c < FIN_MAX_CHUNKS && c * N < 2048) c *= 2;
+  return c;
+}
 __global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restrict__ lpart, const void* __restrict__ gt,
                                                            int tt, int HW, int RB, int h16, float* __restrict__ part2) {
   __shared__ float s_red[TPB][5];
-  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, FIN_CHUNKS = gridDim.x;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, gs = 0.f;
   const float4* p = lpart + (size_t)n * tt * 4;
   const int np = tt * 4, p_lo = (int)((long long)np * ch / FIN_CHUNKS), p_hi = (int)((long long)np * (ch + 1) / FIN_CHUNKS);
@@ -1878,7 +1883,7 @@ __global__ __launch_bounds__(TPB) void k_sil_loss_finish1(const float4* __restri
   }
   if (tid < 5) part2[((size_t)n * FIN_CHUNKS + ch) * 5 + tid] = s_red[0][tid];
 }
-__global__ void k_sil_loss_finish2(const float* __restrict__ part2, int N, int HW, float* __restrict__ out) {
+__global__ void k_sil_loss_finish2(const float* __restrict__ part2, int N, int HW, int FIN_CHUNKS, float* __restrict__ out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1898,7 +1903,7 @@ __global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restri
                                                            const void* __restrict__ tmask, int tt, int HW, int RB,
                                                            int h16, float* __restrict__ part2) {
   __shared__ float s_red[TPB];
-  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, FIN_CHUNKS = gridDim.x;
   float acc = 0.f;
   const float4* p = lpart + (size_t)n * tt * 4;
   const int t_lo = (int)((long long)tt * ch / FIN_CHUNKS), t_hi = (int)((long long)tt * (ch + 1) / FIN_CHUNKS);
@@ -1946,7 +1951,7 @@ __global__ __launch_bounds__(TPB) void k_tex_loss_finish1(const float4* __restri
   }
   if (tid == 0) part2[(size_t)n * FIN_CHUNKS + ch] = s_red[0];
 }
-__global__ void k_tex_loss_finish2(const float* __restrict__ part2, int N, int HW, float* __restrict__ out) {
+__global__ void k_tex_loss_finish2(const float* __restrict__ part2, int N, int HW, int FIN_CHUNKS, float* __restrict__ out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float a = 0.f;
@@ -2471,9 +2476,10 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   if (rc || !fused) return rc;
   const int tiles = (H + RBLK - 1) / RBLK;
   ProfScope ps(ACFM_PROF_MASK_LOSS, st);
-  hipLaunchKernelGGL(k_sil_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, gt, tiles * tiles, H * H,
+  const int fc = fin_chunks(N);
+  hipLaunchKernelGGL(k_sil_loss_finish1, dim3(fc, N), dim3(TPB), 0, st, ws.lpart, gt, tiles * tiles, H * H,
                      ref_batch, out.h16, ws.lpart2);
-  hipLaunchKernelGGL(k_sil_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, losses);
+  hipLaunchKernelGGL(k_sil_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, fc, losses);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -2629,9 +2635,10 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
   if (loss) {
     const int tiles = (H + RBLK - 1) / RBLK;
     ProfScope ps(ACFM_PROF_TEX_MSE, st);
-    hipLaunchKernelGGL(k_tex_loss_finish1, dim3(FIN_CHUNKS, N), dim3(TPB), 0, st, ws.lpart, ref_img, ref_mask,
+    const int fc = fin_chunks(N);
+    hipLaunchKernelGGL(k_tex_loss_finish1, dim3(fc, N), dim3(TPB), 0, st, ws.lpart, ref_img, ref_mask,
                        tiles * tiles, H * H, ref_batch, out.h16, ws.lpart2);
-    hipLaunchKernelGGL(k_tex_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, loss);
+    hipLaunchKernelGGL(k_tex_loss_finish2, dim3((N + 63) / 64), dim3(64), 0, st, ws.lpart2, N, H * H, fc, loss);
     ACFM_CHECK_LAUNCH();
   }
   return ACFM_OK;

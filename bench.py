@@ -37,13 +37,20 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--frames", type=int, default=64, help="frames per GPU")
-    p.add_argument("--img", type=int, default=256)
+    p.add_argument("--config", type=int, default=2, choices=(2, 5),
+                   help="BASELINE.json configs[1] (default: bird, 64 frames @256^2, fp32, drop-in API) or configs[4], one "
+                        "GPU's share of it (5120-face subdivided horse, 16 frames @512^2, half storage with fp32 loss sums, "
+                        "fused render+loss operators)")
+    p.add_argument("--frames", type=int, default=None, help="frames per GPU (64; config 5: 16)")
+    p.add_argument("--img", type=int, default=None, help="image size (256; config 5: 512)")
     p.add_argument("--handles", type=int, default=16)
     p.add_argument("--tex", type=int, default=1, help="include the atlas-texture render + loss")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-oracle time budget")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-lean", action="store_true", help="skip the nearest-plane-only comparison run")
+    p.add_argument("--headline-only", action="store_true",
+                   help="only the headline step and its per-kernel timing (profiling runs: every launch of a kernel in the "
+                        "trace then belongs to the same workload)")
     p.add_argument("--eager", action="store_true",
                    help="launch every kernel of the step from Python instead of replaying one captured hipGraph")
     p.add_argument("--learn-lbs", action="store_true",
@@ -97,9 +104,19 @@ def main():
     from acfm_video_3d_reconstruction_amd.sharding import SharedGradReducer
     from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
 
+    cfg5 = a.config == 5
+    if a.headline_only:
+        a.no_lean = a.no_cpu = True
+    a.frames = a.frames or (16 if cfg5 else 64)
+    a.img = a.img or (512 if cfg5 else 256)
     N, H, Kh = a.frames, a.img, a.handles
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
     v_np, f_np = m["bird_v"], m["bird_f"]
+    if cfg5:   # one SubdivideMeshes pass of the horse template: 2562 verts / 5120 faces (the shim's restatement of pytorch3d.ops)
+        from acfm_video_3d_reconstruction_amd.pytorch3d_shim.ops import SubdivideMeshes
+        from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
+        sub = SubdivideMeshes()(Meshes(verts=[torch.tensor(m["horse_v"])], faces=[torch.tensor(m["horse_f"])]))
+        v_np, f_np = sub.verts_packed().numpy().astype(np.float32), sub.faces_packed().numpy().astype(np.int64)
     V, F = v_np.shape[0], f_np.shape[0]
     rng = np.random.default_rng(1000 + rank)
     ext = float(np.abs(v_np).max())
@@ -111,13 +128,13 @@ def main():
     solver = DeformSolver(mean_v, faces[0], lbs_logits)
     delta0 = torch.tensor(rng.normal(0, 0.02, (N, Kh, 3)).astype(np.float32), device=dev)
     cams0 = torch.tensor(make_cams(N, rng, extent=ext), device=dev)
-    renderer = NeuralRenderer(H)
+    renderer = NeuralRenderer(H, storage="f16") if cfg5 else NeuralRenderer(H)
     with torch.no_grad():  # GT = own render of a differently perturbed pose, thresholded
         gt_delta = torch.tensor(rng.normal(0, 0.03, (N, Kh, 3)).astype(np.float32), device=dev)
         gt_cams = cams0.clone()
         gt_cams[:, 1:3] += torch.tensor(rng.uniform(-0.03, 0.03, (N, 2)).astype(np.float32), device=dev)
         gt_mask, _ = renderer(solver(gt_delta), faces, gt_cams)
-        gt_mask = (gt_mask > 0.5).float()
+        gt_mask = (gt_mask.float() > 0.5).float()
     edt, bds = edt_and_boundaries(gt_mask)
     imgs_gt = torch.tensor(rng.uniform(0, 1, (N, 3, H, H)).astype(np.float32), device=dev)
     R = 6
@@ -132,8 +149,21 @@ def main():
 
     side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
 
+    if cfg5:   # references and atlas held in half by the caller (what ACFM_STORE_F16 reads); the atlas gradient stays float
+        gt_h, edt_h, imgs_h = gt_mask.half(), edt.half(), imgs_gt.half()
+
     def compute(ren, fused=False):
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
+        if cfg5:
+            sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_h, edt_h, raw=True)
+            bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
+            tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_h, gt_h)[0]
+            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
+            g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+            if world > 1:
+                flat_views[0].copy_(g_mean)
+                flat_extra.copy_(total.detach().reshape(1))
+            return total.detach(), g_delta, g_cams, g_mean, g_atlas
         tex_term = None
         if side is not None:
             # experiment (off by default): the texture branch reads detached geometry only
@@ -284,46 +314,49 @@ def main():
     value = world * N * a.steps / dt
     use_graph = not a.eager and side is None
     # the other launch mode of the same step, reported beside the headline (never instead of it)
-    dt_other = timed(renderer, max(2, a.warmup // 2), a.steps, use_graph=not use_graph) if side is None else None
+    extras = not cfg5 and not a.headline_only
+    dt_other = timed(renderer, max(2, a.warmup // 2), a.steps, use_graph=not use_graph) if side is None and extras else None
     # same step with only the nearest-face plane of pix_to_face written (all that any caller of
     # the reference reads); reported beside the headline value, never instead of it
     dt_lean = None
-    if not a.no_lean:
+    if not a.no_lean and not cfg5:
         lean = NeuralRenderer(H, pix_to_face_slots=1)
         dt_lean = timed(lean, max(2, a.warmup // 2), a.steps)
 
     # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
     # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
-    dt_fused = timed(renderer, max(2, a.warmup // 2), a.steps, fused=True) if side is None else None
+    dt_fused = timed(renderer, max(2, a.warmup // 2), a.steps, fused=True) if side is None and extras else None
 
     # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
     # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
-    rv = solver(delta0).detach().requires_grad_(True)
-    rc = cams0.clone().requires_grad_(True)
-    rw = torch.randn(N, H, H, device=dev) / (H * H)
+    dt_render = None
+    if extras:
+        rv = solver(delta0).detach().requires_grad_(True)
+        rc = cams0.clone().requires_grad_(True)
+        rw = torch.randn(N, H, H, device=dev) / (H * H)
 
-    def render_only():
-        m, _ = renderer(rv, faces, rc)
-        return torch.autograd.grad((m * rw).sum(), [rv, rc])
-    for _ in range(max(2, a.warmup // 2)):
-        render_only()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        render_only()
-    fence()
-    dt_render = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt_render], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_render = float(t.item())
+        def render_only():
+            m, _ = renderer(rv, faces, rc)
+            return torch.autograd.grad((m * rw).sum(), [rv, rc])
+        for _ in range(max(2, a.warmup // 2)):
+            render_only()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            render_only()
+        fence()
+        dt_render = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_render], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_render = float(t.item())
 
     # ---- SURVEY section 8d's step, every row of it: the headline step + the per-optimiser-step factorisation
     # of the deformation system with learned handle weights (a8: cot Laplacian, fp64 Cholesky, lbs gradient)
     # + the mesh priors on the deformed shape (a14 locally_rigid_fn, a15 mesh_laplacian_smoothing 'cot');
     # reported beside the headline value, never instead of it
     dt_full = None
-    if a.tex and side is None:
+    if a.tex and side is None and extras:
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.loss import mesh_laplacian_smoothing
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
         lbs_p = torch.nn.Parameter(lbs_logits.clone())
@@ -404,32 +437,57 @@ def main():
             "k_tex_bwd": N * (12 * H * H + 4 * H * H + 12 * F * R * R),
             "k_mask_losses": N * 12 * H * H, "k_mask_losses_bwd": N * 16 * H * H,
         }
+        if cfg5:   # half storage, int32 nearest-face plane, fused losses (SURVEY 8d with the halved terms)
+            alg = {
+                # write mask 2H^2 + id 4H^2, read gt 2H^2 + edt 2H^2, verts 12V, cam 28 (+ faces 12F once)
+                "k_raster_fwd<K,soft>": N * (10 * H * H + 12 * V + 28) + 12 * F,
+                # read mask 2H^2 + gt 2H^2 + edt 2H^2 (no mask gradient: formed in the kernel), write grads 12V + 28
+                "k_sil_bwd": N * (6 * H * H + 12 * V + 28),
+                # read atlas 6FR^2 + reference image 6H^2 + mask 2H^2; write image 6H^2 + sil 2H^2 + id 4H^2
+                "k_raster_fwd<1,tex>": N * (20 * H * H + 6 * F * R * R + 12 * V + 28),
+                # read image 6H^2 + reference 6H^2 + mask 2H^2; write the float atlas gradient 12FR^2
+                "k_tex_bwd": N * (14 * H * H + 12 * F * R * R),
+            }
         ab = alg.get(dom, 0)
         ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
         # the committed measurement of the same workload (rocprofv3 --pmc, separate passes) is quoted
-        traffic, traffic_src, valu_insts = None, None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            w = pm["workload"]
-            if (w["frames"], w["img"], w["K"]) == (N, H, 20) and dom in pm["kernels"]:
-                traffic = pm["kernels"][dom]["fetch_bytes"] + pm["kernels"][dom]["write_bytes"]
-                traffic_src = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch)"
-                valu_insts = pm["kernels"][dom].get("valu_insts")
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src, pmk = None, None, None
+        for tag in ("r02", "r01"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)))
+                w = pm["workload"]
+                same = (w["frames"], w["img"], w["K"], w.get("mesh", "bird"), w.get("storage", "f32")) == \
+                       (N, H, 20, "horse_subdiv1" if cfg5 else "bird", "f16" if cfg5 else "f32")
+                if same and dom in pm["kernels"]:
+                    pmk = pm["kernels"][dom]
+                    traffic = pmk["fetch_bytes"] + pmk["write_bytes"]
+                    traffic_src = "profiles/%s_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch, own --pmc passes)" % tag
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
-        if valu_insts:
-            # The kernel is bound by VALU issue, not by HBM: a wave64 VALU instruction occupies its SIMD
-            # for 4 cycles, 1024 SIMDs at 2.4 GHz issue 614 G of them per second (MI355X_MICROARCH.md).
-            # SQ_INSTS_VALU per launch from the committed PMC pass of the same workload.
-            peak = 1024 * 2.4e9 / 4
-            rate = valu_insts / (kern[dom]["avg_us"] * 1e-6)
-            roof["valu"] = dict(insts_per_launch=valu_insts, achieved_ginst_s=round(rate / 1e9, 1),
-                                peak_ginst_s=round(peak / 1e9, 1), frac=round(rate / peak, 4),
-                                source="profiles/r01_pmc_traffic.json (SQ_INSTS_VALU, own --pmc pass)")
+        if pmk and pmk.get("valu_insts"):
+            # What limits the kernel is VALU issue, not HBM.  Issue rates measured on this part with independent
+            # instruction streams at 4 waves per SIMD (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt):
+            # fp32 add / mul / fma, integer add, and: 1.21 ns per wave-instruction and SIMD (844 G/s on 1024 SIMDs);
+            # selects, compares, min / max / med3, shifts, 64-bit moves, DPP, packed fp32: 1.75-1.95 ns (525-585 G/s);
+            # rcp / exp / sqrt: 3.5 ns (293 G/s).  The raster kernels' stream is mostly the second class (the sorted
+            # insertion is one 64-bit compare + six selects per slot), so its ceiling lies between the two figures.
+            rate = pmk["valu_insts"] / (kern[dom]["avg_us"] * 1e-6)
+            v = dict(insts_per_launch=pmk["valu_insts"], achieved_ginst_s=round(rate / 1e9, 1),
+                     full_rate_ginst_s=844.4, half_rate_class_ginst_s=572.7,
+                     frac_of_full_rate=round(rate / 844.4e9, 4), frac_of_half_rate_class=round(rate / 572.7e9, 4),
+                     source=traffic_src.split(" ")[0] + " (SQ_INSTS_VALU), profiles/r02_valu_rates.txt (rates)")
+            if pmk.get("active_inst_valu") and pmk.get("grbm_gui_active"):
+                # SQ_ACTIVE_INST_VALU counts quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                v["valu_busy"] = round(pmk["active_inst_valu"] * 4 / (1024 * pmk["grbm_gui_active"] / 8), 4)
+            if pmk.get("thread_cycles_valu") and pmk.get("active_inst_valu"):
+                v["lanes_active"] = round(pmk["thread_cycles_valu"] / (64 * pmk["active_inst_valu"]), 4)
+            roof["valu"] = v
+            roof["limiter"] = "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)"
         if traffic:   # what the kernel actually moves (the API's K int64 ids per pixel dominate): context, not `achieved`
             moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
@@ -457,13 +515,18 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "frames/s differentiable render+bwd, 642-vert mesh @256^2, batch=64",
+            "metric": "frames/s differentiable render+bwd, 5k-face mesh @512^2, 16 frames/GPU (config 5 shard)" if cfg5 else
+                      "frames/s differentiable render+bwd, 642-vert mesh @256^2, batch=64",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CUB bird template (642 v / 1280 f), %d frames/GPU @%dx%d, deform apply + "
-                                   "soft silhouette K=20 + L1/IoU/EDT + boundary loss%s, fwd+bwd" %
-                                   (N, H, H, " + atlas texture render/MSE" if a.tex else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (half storage)" if cfg5 else "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE config 5, one GPU's share: subdivided horse template (%d v / %d f), %d frames/GPU "
+                                    "@%dx%d, half storage with fp32 loss sums, deform apply + fused soft silhouette K=20 / L1 / "
+                                    "IoU / EDT + boundary loss + fused atlas texture render / MSE, fwd+bwd" % (V, F, N, H, H))
+                       if cfg5 else
+                       "CUB bird template (642 v / 1280 f), %d frames/GPU @%dx%d, deform apply + "
+                       "soft silhouette K=20 + L1/IoU/EDT + boundary loss%s, fwd+bwd" %
+                       (N, H, H, " + atlas texture render/MSE" if a.tex else ""),
                        "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
                        "sharding": "frames over ranks; all-reduce of shared mean-shape grad"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
@@ -475,11 +538,12 @@ def main():
             out["hipgraph_replay" if not use_graph else "eager_launch"] = {
                 "value": round(world * N * a.steps / dt_other, 2), "unit": "frames/s",
                 "ms_per_step": round(1e3 * dt_other / a.steps, 4)}
-        out["render_only"] = {
-            "value": round(world * N * a.steps / dt_render, 2), "unit": "frames/s",
-            "ms_per_step": round(1e3 * dt_render / a.steps, 4),
-            "note": "soft-silhouette render K=20 (pix_to_face [N,H,W,20] materialised) + backward to vertices and "
-                    "cameras only; eager launches"}
+        if dt_render:
+            out["render_only"] = {
+                "value": round(world * N * a.steps / dt_render, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * dt_render / a.steps, 4),
+                "note": "soft-silhouette render K=20 (pix_to_face [N,H,W,20] materialised) + backward to vertices and "
+                        "cameras only; eager launches"}
         if dt_full:
             out["survey_8d_step"] = {
                 "value": round(world * N * a.steps / dt_full, 2), "unit": "frames/s",
