@@ -40,6 +40,21 @@
 
 namespace acfm {
 
+// Diagnostic event counters (make VARIANT=count EXTRA="-DACFM_DIAG -DACFM_DIAG_COUNT", tools/count_events.py): what a
+// launch of the K-nearest forward actually executes -- walk iterations, how many reach each stage, with how many
+// live lanes, how many 4-slot blocks of the sorted insertion run.  Not in the shipping build.
+#ifdef ACFM_DIAG_COUNT
+__device__ unsigned long long g_diag[16];
+#define DIAG_ADD(i, v)                                                                              \
+  do {                                                                                              \
+    const unsigned long long v_ = (unsigned long long)(v);   /* (evaluated by every active lane: v may hold a ballot) */ \
+    const unsigned long long m_ = __ballot(true);                                                   \
+    if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(m_)) atomicAdd(&g_diag[i], v_);             \
+  } while (0)
+#else
+#define DIAG_ADD(i, v) do {} while (0)
+#endif
+
 // A raster launch has entries / div workgroups per XCD group (see Sched; div = Tune::div of the call): the
 // flagged-empty blocks -- 70 % of a 256^2 frame of the bird -- cost no workgroup dispatch of their own.
 constexpr int RBLK = 8;       // pixels per block side: one wave64 per block
@@ -664,6 +679,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
     const bool have = i < my_n;
     const bool in_box = have &&
         !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
+    DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(in_box))); DIAG_ADD(10, __popcll(__ballot(have)));
     body(cur, in_box, i);
   }
 }
@@ -934,7 +950,9 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
   // smaller, nothing moves in these four slots (the new face lies deeper than all of them in every
   // lane -- faces arrive in id order, not in depth order) and the block costs one compare.
   constexpr int HI = (LO + 4 < K ? LO + 4 : K);
+  DIAG_ADD(9, 1);
   if (__ballot(x < key[HI - 1]) != 0ull) {
+    DIAG_ADD(8, 1);
 #pragma unroll
     for (int k = LO; k < HI; ++k) {
 #if ACFM_ASM_SLOT
@@ -1465,7 +1483,9 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     });
 #else
     unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
+    DIAG_ADD(0, 1);
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
+      DIAG_ADD(1, 1); DIAG_ADD(2, list_n);
 #ifdef ACFM_DIAG_NO_WALK
       if (list_n >= 0) { seen += list_n; return; }
 #endif
@@ -1484,12 +1504,14 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         unsigned long long x = make_key(h.pz, cd.fid);
         live = live && (x < key[K - 1]);
         if (__ballot(live) == 0ull) return;
+        DIAG_ADD(5, 1); DIAG_ADD(6, __popcll(__ballot(live)));
         if (!live) return;
 #ifdef ACFM_DIAG_NO_STAGE2
         h.sd = h.pz;
 #else
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
 #endif
+        DIAG_ADD(7, __popcll(__ballot(true))); DIAG_ADD(11, 1);
         float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma, sig_scale);
 #ifdef ACFM_DIAG_NO_INSERT
         if (x < key[0]) { key[0] = x; q[0] = xq; }
@@ -2326,6 +2348,16 @@ extern "C" {
 
 // Diagnostic builds only (make DIAG=1 -> libacfm_hip_diag.so, used by tools/stamps.py and tools/occ_probe.py):
 // per-workgroup time stamps and the occupancy query.  The shipping library has no such state.
+#ifdef ACFM_DIAG_COUNT
+int acfm_debug_counters(unsigned long long* host16, int reset) {
+  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(acfm::g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return ACFM_E_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(acfm::g_diag), z, sizeof(z)) != hipSuccess) return ACFM_E_LAUNCH;
+  }
+  return ACFM_OK;
+}
+#endif
 #ifdef ACFM_DIAG
 static unsigned long long* g_dbg = nullptr;
 int acfm_debug_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)p; return 0; }
@@ -2334,7 +2366,7 @@ int acfm_debug_occupancy(int which, int dyn_lds) {
   hipError_t e = hipSuccess;
   if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<20, false, false>, RT, 0);
   else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster_fwd<1, true, true>, RT, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sil_bwd, RT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sil_bwd<float>, RT, 0);
   return e == hipSuccess ? n : -1;
 }
 #else

@@ -1,0 +1,29 @@
+"""Diagnostic: event counters of the K-nearest forward on the headline workload (needs the counting build:
+make -C acfm_video_3d_reconstruction_amd/csrc VARIANT=count EXTRA="-DACFM_DIAG -DACFM_DIAG_COUNT";
+ACFM_LIB=.../libacfm_hip_count.so python tools/count_events.py)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from acfm_video_3d_reconstruction_amd import _lib, ops
+from acfm_video_3d_reconstruction_amd.synthetic import batch_verts, make_cams
+assert _lib.SO_PATH.endswith("_count.so"), "run with ACFM_LIB=<libacfm_hip_count.so>"
+raw = ctypes.CDLL(_lib.SO_PATH)
+d = torch.device("cuda:0")
+m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz")); v, f = m["bird_v"], m["bird_f"]
+rng = np.random.default_rng(1000); N, H = 64, 256
+verts = torch.tensor(batch_verts(v, N, rng, 0.005), device=d)
+cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
+faces = torch.tensor(f, device=d)[None].repeat(N, 1, 1).contiguous()
+ops.sil_render(verts, faces, cams, H); torch.cuda.synchronize()
+c = (ctypes.c_ulonglong * 16)()
+raw.acfm_debug_counters(c, 1)
+mask, p2f = ops.sil_render(verts, faces, cams, H); torch.cuda.synchronize()
+raw.acfm_debug_counters(c, 0)
+names = ["blocks with work", "walk calls", "candidates (sum list_n)", "walk iterations (wave)", "lanes in_box", "iterations reaching stage 2",
+         "lanes live (stage 2)", "lanes accepted", "insertion blocks executed", "insertion block tests", "lanes having a face", "iterations inserting"]
+for i, n in enumerate(names): print("%-32s %12d" % (n, c[i]))
+it = c[3]
+print("per iteration: lanes with a face %.1f, in_box %.1f, live %.1f (of the %.0f%% of iterations that reach stage 2), accepted %.1f; "
+      "insertion blocks per inserting iteration %.2f" % (c[10] / it, c[4] / it, c[6] / max(c[5], 1), 100.0 * c[5] / it, c[7] / max(c[11], 1), c[8] / max(c[11], 1)))
+cov = (p2f[..., 0] >= 0).sum().item(); kept = (p2f >= 0).sum().item()
+print("covered pixels %d, kept (pixel, face) pairs %d (%.1f per covered pixel); accepted pairs %d" % (cov, kept, kept / cov, c[7]))
