@@ -28,6 +28,8 @@
 // identity / R.  Indices in [n, n_pad) are padded with the identity.
 #include "acfm_common.h"
 
+#include <atomic>
+
 #pragma clang fp contract(fast)  // fp64 solve: fused multiply-adds are welcome here
 
 namespace acfm {
@@ -109,32 +111,33 @@ __device__ __forceinline__ f64x4 tile_mma(int lane, f64x4 acc, FA&& fa, FB&& fb)
 }
 
 // One wave factorises the SPD tile in sC (lower part read) in place and inverts the factor.
-// On return sC = L (upper part zero), sX = L^-1.  Lanes 0-31: lane r builds row r of L
-// (left-looking: L_rj = (C_rj - sum_{p<j} L_rp L_jp) / L_jj); lanes 32-63: lane 32+c builds
-// column c of L^-1 by forward substitution (x_j = (delta_jc - sum_{p<j} L_jp x_p) / L_jj).  Both
-// recurrences are  u_j = (init - sum_{p<j} u_p L_jp) / L_jj  with the same wave-uniform L_jp, so
-// one instruction stream serves both halves.  Row j of L is read back from LDS (two entries per
-// ds_read_b128, same address in every lane) except its newest entry L_j,j-1, which comes straight
-// from lane j's register so that no LDS round trip sits on the pivot chain.  1/sqrt by v_rsq_f64 +
-// two Newton steps (no IEEE divide / sqrt sequences on the serial chain).
+// On return sC = L^T (row j = column j of L, zero left of the diagonal), sX = L^-1.
+// Lanes 0-31: lane r owns row r of L; lanes 32-63: lane 32+c owns column c of L^-1 (forward
+// substitution).  Both are the recurrence  u_j = (c_j - sum_{p<j} u_p L_jp) / L_jj  with the same
+// wave-uniform L_jp, so one instruction stream serves both halves.  Right-looking: once u_j is known,
+// every later start value takes its term  c_q -= u_j L_qj  at once; these updates are independent of
+// each other, so the serial chain per pivot is only: pivot broadcast, 1/sqrt by v_rsq_f64 + two Newton
+// steps (no IEEE divide / sqrt sequences), one multiply, and the updates of the next two start values
+// with L_qj taken from lane q's register (v_readlane).  The updates further out read L_qj back from
+// LDS (row j of L^T, two entries per ds_read_b128, same address in every lane) and are issued one
+// pivot LATER (phase 3 below), when that data has long arrived, so no LDS round trip and no
+// s_waitcnt sits on the chain.  No lane-dependent branch: the unrolled loop is one basic block.
 __device__ __forceinline__ void potrf32_inv(double (*sC)[LDT], double (*sX)[LDT], int lane, int base_index, int* info) {
   const int r = lane & 31;
   const bool low = lane < 32;
-  double u[NB];
-  bool bad = false;
+  double c[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    double s0 = low ? sC[r][j] : (r == j ? 1.0 : 0.0), s1 = 0.0;
-    int p = 0;
+    const double cj = sC[r][j];
+    c[j] = low ? cj : (r == j ? 1.0 : 0.0);
+  }
+  double* wp = low ? &sC[0][r] : &sX[0][r];  // u_j goes to row j, column r of L^T / of the inverse
+  bool bad = false;
+  double lrow[NB], lrow_prev[NB], u_prev = 0.0;
 #pragma unroll
-    for (; p + 2 <= j - 1; p += 2) {
-      const double2 l = *reinterpret_cast<const double2*>(&sC[j][p]);
-      s0 -= u[p] * l.x;
-      s1 -= u[p + 1] * l.y;
-    }
-    if (p < j - 1) s1 -= u[p] * sC[j][p];
-    if (j > 0) s0 -= u[j - 1] * bcast_lane(u[j - 1], j);
-    const double sum = s0 + s1;
+  for (int j = 0; j < NB; ++j) {
+    // ---- phase 1, the chain: u_j from the finished start value
+    const double sum = c[j];
     const double piv = bcast_lane(sum, j);
     bad = bad || !(piv > 0.0);
     double y = __builtin_amdgcn_rsq(piv);
@@ -144,14 +147,32 @@ __device__ __forceinline__ void potrf32_inv(double (*sC)[LDT], double (*sX)[LDT]
     double v = sum * y;
     v = (low && r == j) ? piv * y : v;
     v = (low && r < j) ? 0.0 : v;
-    u[j] = v;
-    if (low) sC[r][j] = v;
+    if (j + 1 < NB) c[j + 1] -= v * bcast_lane(v, j + 1);
+    if (j + 2 < NB) c[j + 2] -= v * bcast_lane(v, j + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: publish u_j, ask for row j of L^T beyond the two entries taken from registers
+    wp[j * LDT] = v;
+    {
+      int q = j + 3;
+      if (q < NB && (q & 1)) { lrow[q] = sC[j][q]; ++q; }
+#pragma unroll
+      for (; q + 2 <= NB; q += 2) {
+        const double2 l = *reinterpret_cast<const double2*>(&sC[j][q]);
+        lrow[q] = l.x;
+        lrow[q + 1] = l.y;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: the far updates of pivot j - 1 (its row was requested one pivot ago)
+    if (j > 0) {
+#pragma unroll
+      for (int q = j + 2; q < NB; ++q) c[q] -= u_prev * lrow_prev[q];
+    }
+    u_prev = v;
+#pragma unroll
+    for (int q = j + 3; q < NB; ++q) lrow_prev[q] = lrow[q];
   }
   if (bad && lane == 0) atomicMax(info, base_index + 1);
-  if (!low) {
-#pragma unroll
-    for (int p = 0; p < NB; ++p) sX[p][r] = u[p];
-  }
 }
 
 // ---- A = softmax(lbs[:, h]) over the vertices, fp64; grid = 32 (rows >= Kh are zero) ----------
@@ -160,9 +181,11 @@ __global__ __launch_bounds__(256) void k_solve_softmax(const float* __restrict__
   const int h = blockIdx.x, t = threadIdx.x;
   double* rowW = s.W + (size_t)(s.n_pad + h) * s.ld;
   double* rowA = s.A64 + (size_t)h * s.n_pad;
-  if (h == 0 && t == 0) *s.info = 0;
+  if (h == 0 && t == 0) { s.info[0] = 0; s.info[1] = 0; }  // status, tile ticket of k_chol_tiles
+#if ACFM_CHOL_STEPS
   // identity under the right-hand sides (the region was zeroed by the host): R = L^-T rides along
   for (int v = h * 256 + t; v < s.n_pad; v += KHP * 256) s.W[(size_t)(s.n_pad + NB + v) * s.ld + v] = 1.0;
+#endif
   if (h >= Kh) {
     for (int v = t; v < s.n_pad; v += 256) rowW[v] = rowA[v] = 0.0;
     return;
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(256) void k_chol_first(SolveWs s) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-    s.Lf[(size_t)rr * s.ld + cc] = sA[rr][cc];
+    s.Lf[(size_t)rr * s.ld + cc] = sA[cc][rr];  // potrf32_inv leaves L^T
     s.Linv[rr * NB + cc] = sB[rr][cc];
   }
 }
@@ -316,9 +339,210 @@ __global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sWi[rr][cc];
+      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sWi[cc][rr];  // potrf32_inv leaves L^T
       invn[rr * NB + cc] = sWj[rr][cc];
     }
+  }
+}
+
+// ---- the factorisation as ONE launch: tiles as dataflow ------------------------------------------
+// Every tile (i, j) of the factor (matrix rows, the right-hand-side row, the identity rows that become
+// R = L^-T) is one job:   acc = W_ij - sum_{k<j} L_ik L_jk^T   (k ascending, the order of the trailing
+// updates of a right-looking sweep),  then  L_ij = acc L_jj^-T  (diagonal: factorise + invert).
+// Jobs are handed out by a ticket in column-major order (column j: diagonal, matrix rows below it,
+// right-hand sides, identity rows 0..j), so a job depends only on jobs with a lower ticket: whichever
+// workgroup holds the lowest unfinished ticket can always finish, with any number of resident
+// workgroups and any dispatch order.
+//
+// Hand-off without flags or fences: Lf and Linv are pre-filled with a sentinel (all-ones, a NaN no
+// arithmetic produces); producers write every word of a finished tile with one agent-scope (sc1,
+// write-through) 8-byte store, consumers read operands with agent-scope 8-byte loads straight into
+// the MFMA operand registers and repeat until no lane holds the sentinel.  Each word validates itself,
+// so no ordering between words is needed.  Off the critical path a wave first polls one word of the
+// tile it waits for (one 8-byte request per poll instead of 8 KB).
+//
+// Critical path: the diagonal job of column c also carries the tile left of it, (c, c-1), so that after
+// L_{c-1,c-1}^-1 arrives it needs no second hand-off:  L_{c,c-1} = acc2 Linv^T,  acc -= L_{c,c-1} L_{c,c-1}^T,
+// factorise.  (The job of tile (c, c-1) computes the same tile for everybody else.)
+// Spins are bounded: on expiry the job raises CHOL_E_HANDOFF in info and carries on with what it has, so
+// the grid always drains.
+constexpr unsigned long long CHOL_SENTINEL = ~0ull;
+constexpr int CHOL_E_HANDOFF = 0x40000000;
+constexpr int CHOL_SPIN_LIMIT = 1 << 19;
+
+__device__ __forceinline__ unsigned long long ld_word(const double* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_word(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the 8 MFMA operand words of this lane from tile rows [row0 + x], columns 4 m + y
+__device__ __forceinline__ bool ld_operand(const double* tile_row, double (&v)[8]) {
+  bool bad = false;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const unsigned long long u = ld_word(tile_row + 4 * m);
+    bad |= u == CHOL_SENTINEL;
+    v[m] = __longlong_as_double((long long)u);
+  }
+  return bad;
+}
+// wave-uniform wait for one word of a tile; false on expiry
+__device__ __forceinline__ bool gate(const double* word, int& budget) {
+  while (ld_word(word) == CHOL_SENTINEL) {
+    if (--budget < 0) return false;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_solve_prepare(SolveWs s) {
+  // sentinel into every tile k_chol_tiles publishes (and the diagonal inverses); grid = (2 nblk + 1) nblk + nblk
+  const int nb = s.nblk, tiles = (2 * nb + 1) * nb, b = blockIdx.x, t = threadIdx.x;
+  ulonglong2 ones = {CHOL_SENTINEL, CHOL_SENTINEL};
+  if (b >= tiles) {
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(s.Linv + (size_t)(b - tiles) * NB * NB);
+    d[t] = ones; d[t + 256] = ones;
+    return;
+  }
+  const int ti = b / nb, tj = b % nb;
+  const bool used = ti < nb ? tj <= ti : (ti == nb || tj >= ti - nb - 1);
+  if (!used) return;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = t + 256 * e, rr = idx >> 4, cc = (idx & 15) * 2;
+    *reinterpret_cast<ulonglong2*>(s.Lf + (size_t)(NB * ti + rr) * s.ld + NB * tj + cc) = ones;
+  }
+}
+
+#ifdef ACFM_DIAG
+#define CHOL_STAMP(slot) do { if (diag && t == 0) reinterpret_cast<long long*>(s.Z)[8 * j + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define CHOL_STAMP(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s) {
+  __shared__ __attribute__((aligned(16))) double sP[NB][LDT], sQ[NB][LDT];
+  __shared__ int s_ticket;
+  const int nb = s.nblk, ntiles = nb * (nb + 2), ld = s.ld;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int qi = w >> 1, qj = w & 1, x = lane & 15, y = lane >> 4;
+  const int col = 16 * qj + x;
+  const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+  int budget = CHOL_SPIN_LIMIT;  // polls this wave may still spend waiting
+  bool expired = false;
+  for (;;) {
+    if (t == 0) s_ticket = atomicAdd(s.info + 1, 1);
+    __syncthreads();
+    const int b = s_ticket;
+    __syncthreads();
+    if (b >= ntiles) break;
+    const int j = b / (nb + 2), yy = b % (nb + 2);
+    const int i = yy < nb - j ? j + yy : (yy == nb - j ? nb : nb + 1 + (yy - (nb - j) - 1));
+    const bool diag = i == j;
+    const int k0 = i > nb ? i - nb - 1 : 0;  // identity row r: zero left of column r
+    CHOL_STAMP(0);
+    // ---- start value
+    f64x4 acc, acc2 = zero;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * qi + acc_row(lane, e);
+      if (i <= nb) {
+        acc[e] = s.W[(size_t)(NB * i + row) * ld + NB * j + col];
+        if (diag && j > 0) acc2[e] = s.W[(size_t)(NB * i + row) * ld + NB * (j - 1) + col];
+      } else {
+        acc[e] = (j == k0 && row == col) ? 1.0 : 0.0;
+      }
+    }
+    // ---- acc -= L_ik L_jk^T, k ascending; the diagonal job stops one short and feeds (i, j-1) alongside
+    const double* rowA = s.Lf + (size_t)(NB * i + 16 * qi + x) * ld + y;
+    const double* rowB = s.Lf + (size_t)(NB * j + 16 * qj + x) * ld + y;
+    const double* rowB2 = s.Lf + (size_t)(NB * (j > 0 ? j - 1 : 0) + 16 * qj + x) * ld + y;
+    const int kend = diag ? j - 1 : j;
+    for (int k = k0; k < kend; ++k) {
+      double a[8], bb[8], b2[8];
+      for (;;) {
+        bool bad = ld_operand(rowA + NB * k, a);
+        if (diag) {
+          bad |= ld_operand(s.Lf + (size_t)(NB * i + 16 * qj + x) * ld + y + NB * k, bb);
+          bad |= ld_operand(rowB2 + NB * k, b2);
+        } else {
+          bad |= ld_operand(rowB + NB * k, bb);
+        }
+        if (!__any(bad) || expired) break;
+        // wait for a word of each tile, then read again
+        const bool ok = gate(s.Lf + (size_t)(NB * i) * ld + NB * k, budget) &&
+                        gate(s.Lf + (size_t)(NB * (diag ? j - 1 : j)) * ld + NB * k, budget);
+        if (!ok) expired = true;
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc = mfma64(-a[m], bb[m], acc);
+      if (diag) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc2 = mfma64(-a[m], b2[m], acc2);
+      }
+    }
+    // ---- finish
+    CHOL_STAMP(1);
+    const int jd = diag ? j - 1 : j;  // the diagonal inverse this job waits for
+    if (jd >= 0) {
+      double inv[8];
+      const double* rowI = s.Linv + (size_t)jd * NB * NB + (size_t)(16 * qj + x) * NB + y;
+      for (;;) {
+        const bool bad = ld_operand(rowI, inv);
+        if (!__any(bad) || expired) break;
+        if (diag) {  // critical path: poll with the operand loads themselves
+          if (--budget < 0) expired = true;
+          __builtin_amdgcn_s_sleep(1);
+        } else if (!gate(s.Linv + (size_t)jd * NB * NB, budget)) {
+          expired = true;
+        }
+      }
+      CHOL_STAMP(2);
+      const f64x4 src = diag ? acc2 : acc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sP[16 * qi + acc_row(lane, e)][col] = src[e];
+      __syncthreads();
+      f64x4 li = zero;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) li = mfma64(sP[16 * qi + x][4 * m + y], inv[m], li);
+      if (!diag) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          st_word(s.Lf + (size_t)(NB * i + 16 * qi + acc_row(lane, e)) * ld + NB * j + col, li[e]);
+      } else {
+        // acc -= L_{j,j-1} L_{j,j-1}^T
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sQ[16 * qi + acc_row(lane, e)][col] = li[e];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc = mfma64(-sQ[16 * qi + x][4 * m + y], sQ[16 * qj + x][4 * m + y], acc);
+      }
+    }
+    if (diag) {
+      __syncthreads();  // every wave is done with sP / sQ
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sP[16 * qi + acc_row(lane, e)][col] = acc[e];
+      __syncthreads();
+      CHOL_STAMP(3);
+      if (w == 0) potrf32_inv(sP, sQ, lane, NB * i, s.info);
+      __syncthreads();
+      CHOL_STAMP(4);
+      double* invn = s.Linv + (size_t)i * NB * NB;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+        st_word(invn + rr * NB + cc, sQ[rr][cc]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
+        st_word(s.Lf + (size_t)(NB * i + rr) * ld + NB * i + cc, sP[cc][rr]);  // potrf32_inv leaves L^T
+      }
+      CHOL_STAMP(5);
+    }
+    if (expired && lane == 0) atomicOr(s.info, CHOL_E_HANDOFF);
   }
 }
 
@@ -425,6 +649,25 @@ __global__ __launch_bounds__(256) void k_solve_bwd_lbs(SolveWs s, int Kh, float*
 
 using namespace acfm;
 
+#ifndef ACFM_CHOL_STEPS
+#define ACFM_CHOL_STEPS 0  // 1: the factorisation as one launch per tile column (the round-1 path, kept for A/B runs)
+#endif
+
+// workgroups of k_chol_tiles the device holds at once; only a grid size (the ticket makes any number correct)
+static int chol_resident_workgroups() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int cus = 0, per = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_chol_tiles, 256, 0) != hipSuccess || per <= 0) per = 1;
+  v = cus * (per > 4 ? 4 : per);
+  cached[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 extern "C" {
 
 size_t acfm_deform_solve_workspace_bytes(int V, int Kh) {
@@ -439,16 +682,26 @@ int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P,
   if (ws_bytes < s.bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_SOLVE, st);
-  // the identity rows start as zero (k_solve_softmax writes their diagonal)
+#if ACFM_CHOL_STEPS
   if (zero_async(s.W + (size_t)(s.n_pad + NB) * s.ld, sizeof(double) * (size_t)s.n_pad * s.ld, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
+#else
+  hipLaunchKernelGGL(k_solve_prepare, dim3((2 * s.nblk + 2) * s.nblk), dim3(256), 0, st, s);
+#endif
   hipLaunchKernelGGL(k_solve_softmax, dim3(KHP), dim3(256), 0, st, lbs, s, Kh);
   hipLaunchKernelGGL(k_solve_gram_rows, dim3(s.n_pad), dim3(256), 0, st, L, s, Kh);
+#if ACFM_CHOL_STEPS
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, s);
   for (int k = 0; k < s.nblk; ++k) {
     const int m = s.nblk - 1 - k;
     hipLaunchKernelGGL(k_chol_step, dim3(m + 1, s.nblk + 1), dim3(256), 0, st, s, k);
   }
+#else
+  {
+    const int ntiles = s.nblk * (s.nblk + 2), cap = chol_resident_workgroups();
+    hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles < cap ? ntiles : cap), dim3(256), 0, st, s);
+  }
+#endif
   hipLaunchKernelGGL((k_apply_R<false, 0>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)nullptr,
                      (const float*)nullptr, Kh, s.X, P);
   ACFM_CHECK_LAUNCH();
@@ -470,6 +723,15 @@ int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, siz
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
+
+#ifdef ACFM_DIAG
+// diagnostic build only: the 8 clock stamps (10 ns units) of each diagonal job of k_chol_tiles
+int acfm_debug_solve_stamps(const void* ws, int V, long long* out_host, int n) {
+  SolveWs s = carve_solve(const_cast<void*>(ws), V);
+  if (n > 8 * s.nblk) n = 8 * s.nblk;
+  return hipMemcpy(out_host, s.Z, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
+}
+#endif
 
 int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_host, void* stream) {
   if (!ws || !info_host || V <= 0) return ACFM_E_BADARG;

@@ -29,6 +29,9 @@ for name, fn in (("native fwd+bwd", t_native), ("torch fp64 fwd+bwd", t_torch)):
     torch.cuda.synchronize(); print("%-22s %.1f us" % (name, 1e6 * (time.perf_counter() - t0) / a.iters))
 P = ops.deform_solve(L, lbs); R = solve_matrix(L, handle_matrix(lbs))
 print("max |P - P_torch64| / max|P| = %.2e" % float((P.double() - R).abs().max() / R.abs().max()))
+import hashlib
+outs = [ops.deform_solve(L, lbs).cpu().numpy().tobytes() for _ in range(20)]
+print("P sha1 %s  (20 repeats identical: %s)" % (hashlib.sha1(outs[0]).hexdigest()[:12], all(o == outs[0] for o in outs)))
 lib = _lib.lib(); lib.acfm_prof_enable(1)
 for _ in range(a.iters): t_native()
 torch.cuda.synchronize()
