@@ -110,69 +110,91 @@ __device__ __forceinline__ f64x4 tile_mma(int lane, f64x4 acc, FA&& fa, FB&& fb)
   return acc;
 }
 
-// One wave factorises the SPD tile in sC (lower part read) in place and inverts the factor.
-// On return sC = L^T (row j = column j of L, zero left of the diagonal), sX = L^-1.
-// Lanes 0-31: lane r owns row r of L; lanes 32-63: lane 32+c owns column c of L^-1 (forward
-// substitution).  Both are the recurrence  u_j = (c_j - sum_{p<j} u_p L_jp) / L_jj  with the same
-// wave-uniform L_jp, so one instruction stream serves both halves.  Right-looking: once u_j is known,
-// every later start value takes its term  c_q -= u_j L_qj  at once; these updates are independent of
-// each other, so the serial chain per pivot is only: pivot broadcast, 1/sqrt by v_rsq_f64 + two Newton
-// steps (no IEEE divide / sqrt sequences), one multiply, and the updates of the next two start values
-// with L_qj taken from lane q's register (v_readlane).  The updates further out read L_qj back from
-// LDS (row j of L^T, two entries per ds_read_b128, same address in every lane) and are issued one
-// pivot LATER (phase 3 below), when that data has long arrived, so no LDS round trip and no
-// s_waitcnt sits on the chain.  No lane-dependent branch: the unrolled loop is one basic block.
-__device__ __forceinline__ void potrf32_inv(double (*sC)[LDT], double (*sX)[LDT], int lane, int base_index, int* info) {
+// The workgroup (4 waves) factorises the SPD tile sC[NB][LDT] (lower part read) and inverts the factor.
+// On return sU[j][0..31] = column j of L (= row j of L^T, zero left of the diagonal) and
+// sU[j][32..63] = row j of L^-1; sU ([NB][64], 16 KB) may overlay sC and what follows it.
+// Lanes 0-31 of every wave: lane r owns row r of L; lanes 32-63: lane 32+c owns column c of L^-1
+// (forward substitution).  Both are the recurrence  u_j = (c_j - sum_{p<j} u_p L_jp) / L_jj  with the
+// same wave-uniform L_jp, so one instruction stream serves both halves.  A single wave doing all of it
+// is bound by instruction issue (about 75 instructions per pivot, most of them the updates
+// c_q -= u_j L_qj of far columns), so the COLUMNS are dealt to the waves: wave w keeps the start
+// values of columns 8w..8w+7 and runs their eight pivots -- per pivot only the serial chain (pivot
+// broadcast, 1/sqrt by v_rsq_f64 and one second-order correction, no IEEE divide / sqrt sequences)
+// and the updates inside its panel, with L_qj taken from lane q's register (v_readlane) -- publishes
+// each u_j in sU and bumps a counter in LDS.  Before its own panel a wave follows that counter and
+// applies the pivots of the earlier panels to its eight columns (one 64-lane read of u_j, L_qj as
+// broadcast ds_read_b128), off everybody else's chain.
+__device__ __forceinline__ double bcast_lane_dyn(double x, int src) {  // src: wave-uniform
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int PW = 8;  // columns per wave
+#ifdef ACFM_DIAG
+__device__ long long g_potrf_stamps[16];
+#define POTRF_STAMP(slot) do { if (lane == 0) g_potrf_stamps[4 * w + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define POTRF_STAMP(slot) do {} while (0)
+#endif
+__device__ __forceinline__ void potrf32_wg(const double* sC, double* sU, int* sCount, int t, int base_index, int* info) {
+  const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31;
   const bool low = lane < 32;
-  double c[NB];
+  double c[PW];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double cj = sC[r][j];
-    c[j] = low ? cj : (r == j ? 1.0 : 0.0);
+  for (int q = 0; q < PW; ++q) {
+    const double cj = sC[r * LDT + PW * w + q];
+    c[q] = low ? cj : (r == PW * w + q ? 1.0 : 0.0);
   }
-  double* wp = low ? &sC[0][r] : &sX[0][r];  // u_j goes to row j, column r of L^T / of the inverse
+  if (t == 0) *sCount = 0;
+  __syncthreads();  // start values are in registers: sU may overwrite sC from here on
+  POTRF_STAMP(0);
+  // volatile LDS accesses: program order is kept and the LDS executes a wave's accesses in order, which is all
+  // the publish (u_j, then the counter) and the follow (counter, then u_j) need; the explicit address space keeps
+  // them ds_ instructions (a volatile generic pointer becomes a flat system-scope access)
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+  lds_vint* count = (lds_vint*)sCount;
+  lds_vdouble* U = (lds_vdouble*)sU;
+  // ---- the pivots of the earlier panels, as they appear: every poll reads the counter together with the row
+  // of the next pivot, so a published pivot costs one LDS round trip, not two
+  for (int done = 0; done < PW * w;) {
+    const int avail = *count;
+    const double u = U[done * 64 + lane];
+    double l[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) l[q] = U[done * 64 + PW * w + q];
+    if (avail <= done) continue;
+#pragma unroll
+    for (int q = 0; q < PW; ++q) c[q] -= u * l[q];
+    ++done;
+  }
+  // ---- this wave's panel
+  POTRF_STAMP(1);
   bool bad = false;
-  double lrow[NB], lrow_prev[NB], u_prev = 0.0;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    // ---- phase 1, the chain: u_j from the finished start value
-    const double sum = c[j];
-    const double piv = bcast_lane(sum, j);
+  for (int jj = 0; jj < PW; ++jj) {
+    const int j = PW * w + jj;
+    const double sum = c[jj];
+    const double piv = bcast_lane_dyn(sum, j);
     bad = bad || !(piv > 0.0);
-    double y = __builtin_amdgcn_rsq(piv);
-    const double hp = 0.5 * piv;
-    y = y + y * (0.5 - hp * y * y);
-    y = y + y * (0.5 - hp * y * y);
-    double v = sum * y;
-    v = (low && r == j) ? piv * y : v;
-    v = (low && r < j) ? 0.0 : v;
-    if (j + 1 < NB) c[j + 1] -= v * bcast_lane(v, j + 1);
-    if (j + 2 < NB) c[j + 2] -= v * bcast_lane(v, j + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 2: publish u_j, ask for row j of L^T beyond the two entries taken from registers
-    wp[j * LDT] = v;
-    {
-      int q = j + 3;
-      if (q < NB && (q & 1)) { lrow[q] = sC[j][q]; ++q; }
+    // y = piv^-1/2: y0 = rsq, e = 1/2 - piv/2 y0^2, y = y0 (1 + e (1 + 3/2 e)) + O(e^3); the lane's value is
+    // sum * y (lane j: piv * y = the diagonal entry)
+    const double y0 = __builtin_amdgcn_rsq(piv);
+    const double s0 = sum * y0;
+    const double e = 0.5 - (0.5 * piv) * y0 * y0;
+    const double h = e * (1.0 + 1.5 * e);
+    const double v = s0 + s0 * h;
 #pragma unroll
-      for (; q + 2 <= NB; q += 2) {
-        const double2 l = *reinterpret_cast<const double2*>(&sC[j][q]);
-        lrow[q] = l.x;
-        lrow[q + 1] = l.y;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: the far updates of pivot j - 1 (its row was requested one pivot ago)
-    if (j > 0) {
-#pragma unroll
-      for (int q = j + 2; q < NB; ++q) c[q] -= u_prev * lrow_prev[q];
-    }
-    u_prev = v;
-#pragma unroll
-    for (int q = j + 3; q < NB; ++q) lrow_prev[q] = lrow[q];
+    for (int q = jj + 1; q < PW; ++q) c[q] -= v * bcast_lane_dyn(v, PW * w + q);
+    U[j * 64 + lane] = (low && r < j) ? 0.0 : v;
+    *count = j + 1;  // every lane stores the same word: LDS executes a wave's accesses in order
   }
+  POTRF_STAMP(2);
   if (bad && lane == 0) atomicMax(info, base_index + 1);
+  __syncthreads();
+  POTRF_STAMP(3);
 }
 
 // ---- A = softmax(lbs[:, h]) over the vertices, fp64; grid = 32 (rows >= Kh are zero) ----------
@@ -256,21 +278,21 @@ __global__ __launch_bounds__(256) void k_solve_gram_rows(const float* __restrict
 
 // ---- factorise tile (0,0); one WG ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_first(SolveWs s) {
-  __shared__ __attribute__((aligned(16))) double sA[NB][LDT], sB[NB][LDT];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  __shared__ __attribute__((aligned(16))) double sBuf[2 * NB * LDT];
+  __shared__ int sCount;
+  const int t = threadIdx.x;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-    sA[rr][cc] = s.W[(size_t)rr * s.ld + cc];
+    sBuf[rr * LDT + cc] = s.W[(size_t)rr * s.ld + cc];
   }
   __syncthreads();
-  if (w == 0) potrf32_inv(sA, sB, lane, 0, s.info);
-  __syncthreads();
+  potrf32_wg(sBuf, sBuf, &sCount, t, 0, s.info);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-    s.Lf[(size_t)rr * s.ld + cc] = sA[cc][rr];  // potrf32_inv leaves L^T
-    s.Linv[rr * NB + cc] = sB[rr][cc];
+    s.Lf[(size_t)rr * s.ld + cc] = sBuf[cc * 64 + rr];
+    s.Linv[rr * NB + cc] = sBuf[rr * 64 + 32 + cc];
   }
 }
 
@@ -285,7 +307,10 @@ __global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
   const bool panel = (int)blockIdx.x == m;
   const int j = panel ? i : k + 1 + (int)blockIdx.x;
   if (!panel && j > i) return;
-  __shared__ __attribute__((aligned(16))) double sInv[NB][LDT], sWi[NB][LDT], sWj[NB][LDT], sLi[NB][LDT], sLj[NB][LDT];
+  __shared__ __attribute__((aligned(16))) double sInv[NB][LDT], sWW[2][NB][LDT], sLi[NB][LDT], sLj[NB][LDT];
+  __shared__ int sCount;
+  double(*sWi)[LDT] = sWW[0];
+  double(*sWj)[LDT] = sWW[1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int qi = w >> 1, qj = w & 1;
   const double* inv = s.Linv + (size_t)k * NB * NB;
@@ -333,14 +358,14 @@ __global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
   }
   if (next_diag) {
     __syncthreads();
-    if (w == 0) potrf32_inv(sWi, sWj, lane, NB * i, s.info);
-    __syncthreads();
+    double* sU = &sWW[0][0][0];
+    potrf32_wg(sU, sU, &sCount, t, NB * i, s.info);
     double* invn = s.Linv + (size_t)i * NB * NB;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sWi[cc][rr];  // potrf32_inv leaves L^T
-      invn[rr * NB + cc] = sWj[rr][cc];
+      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sU[cc * 64 + rr];
+      invn[rr * NB + cc] = sU[rr * 64 + 32 + cc];
     }
   }
 }
@@ -422,9 +447,60 @@ __global__ __launch_bounds__(256) void k_solve_prepare(SolveWs s) {
 #define CHOL_STAMP(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s) {
-  __shared__ __attribute__((aligned(16))) double sP[NB][LDT], sQ[NB][LDT];
-  __shared__ int s_ticket;
+// P = R Y as the last jobs of the same launch: job c = the 32 vertices of tile row c for all handles,
+//   P[v][h] = sum_{p >= c} sum_q R[32c + v][32p + q] Y^T[h][32p + q],
+// operands read (and awaited) word by word like every other hand-off; the two wave pairs take alternate p and
+// meet in LDS.  Writes X (fp64, the backward's copy) and the fp32 result.
+__device__ __forceinline__ void apply_job(const SolveWs& s, int c, int Kh, float* __restrict__ P, double* sRed /*[2][2][4][64]*/,
+                                          int t, int& budget, bool& expired) {
+  const int lane = t & 63, w = t >> 6, qj = w & 1, par = w >> 1, x = lane & 15, y = lane >> 4;
+  const int nqi = Kh > 16 ? 2 : 1, nb = s.nblk, ld = s.ld;
+  const double* rowR = s.Lf + (size_t)(NB * (nb + 1 + c) + 16 * qj + x) * ld + y;
+  const double* rowY0 = s.Lf + (size_t)(NB * nb + x) * ld + y;
+  const double* rowY1 = rowY0 + (size_t)16 * ld;
+  f64x4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  for (int p = c + par; p < nb; p += 2) {
+    double a0[8], a1[8], bb[8];
+    for (;;) {
+      bool bad = ld_operand(rowR + NB * p, bb) | ld_operand(rowY0 + NB * p, a0);
+      if (nqi > 1) bad |= ld_operand(rowY1 + NB * p, a1);
+      if (!__any(bad) || expired) break;
+      const bool ok = gate(s.Lf + (size_t)(NB * (nb + 1 + c)) * ld + NB * p, budget) &&
+                      gate(s.Lf + (size_t)(NB * nb) * ld + NB * p, budget);
+      if (!ok) expired = true;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      acc[0] = mfma64(a0[m], bb[m], acc[0]);
+      if (nqi > 1) acc[1] = mfma64(a1[m], bb[m], acc[1]);
+    }
+  }
+  if (par == 1) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sRed[((qi * 2 + qj) * 4 + e) * 64 + lane] = acc[qi][e];
+  }
+  __syncthreads();
+  if (par == 0) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (qi >= nqi) continue;
+        const int h = 16 * qi + acc_row(lane, e), v = NB * c + 16 * qj + x;
+        const double r = acc[qi][e] + sRed[((qi * 2 + qj) * 4 + e) * 64 + lane];
+        s.X[(size_t)v * KHP + h] = r;
+        if (v < s.n && h < Kh) P[(size_t)v * Kh + h] = (float)r;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s, int Kh, float* __restrict__ P) {
+  __shared__ __attribute__((aligned(16))) double sPQ[2][NB][LDT];
+  __shared__ int s_ticket, sCount;
+  double(*sP)[LDT] = sPQ[0];
+  double(*sQ)[LDT] = sPQ[1];
   const int nb = s.nblk, ntiles = nb * (nb + 2), ld = s.ld;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int qi = w >> 1, qj = w & 1, x = lane & 15, y = lane >> 4;
@@ -437,7 +513,12 @@ __global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s) {
     __syncthreads();
     const int b = s_ticket;
     __syncthreads();
-    if (b >= ntiles) break;
+    if (b >= ntiles + nb) break;
+    if (b >= ntiles) {
+      apply_job(s, b - ntiles, Kh, P, &sPQ[0][0][0], t, budget, expired);
+      if (expired && lane == 0) atomicOr(s.info, CHOL_E_HANDOFF);
+      continue;
+    }
     const int j = b / (nb + 2), yy = b % (nb + 2);
     const int i = yy < nb - j ? j + yy : (yy == nb - j ? nb : nb + 1 + (yy - (nb - j) - 1));
     const bool diag = i == j;
@@ -526,19 +607,19 @@ __global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s) {
       for (int e = 0; e < 4; ++e) sP[16 * qi + acc_row(lane, e)][col] = acc[e];
       __syncthreads();
       CHOL_STAMP(3);
-      if (w == 0) potrf32_inv(sP, sQ, lane, NB * i, s.info);
-      __syncthreads();
+      double* sU = &sPQ[0][0][0];
+      potrf32_wg(sU, sU, &sCount, t, NB * i, s.info);
       CHOL_STAMP(4);
       double* invn = s.Linv + (size_t)i * NB * NB;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-        st_word(invn + rr * NB + cc, sQ[rr][cc]);
+        st_word(invn + rr * NB + cc, sU[rr * 64 + 32 + cc]);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-        st_word(s.Lf + (size_t)(NB * i + rr) * ld + NB * i + cc, sP[cc][rr]);  // potrf32_inv leaves L^T
+        st_word(s.Lf + (size_t)(NB * i + rr) * ld + NB * i + cc, sU[cc * 64 + rr]);
       }
       CHOL_STAMP(5);
     }
@@ -550,11 +631,12 @@ __global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s) {
 // WG c produces the 32 vertices of tile row c for all handles.  Right-hand sides and results are
 // [n_pad][32] (vertex-major); RHS 0: rhs^T = Y^T in the factor's right-hand-side tile row,
 // 1: an [n_pad][32] fp64 buffer, 2: an fp32 [V][Kh] tensor (the incoming gradient).
+constexpr int APPLY_PAR = 8;  // waves sharing the tile sum of one (vertex tile, handle half)
 template <bool TRANS, int RHS>
-__global__ __launch_bounds__(256) void k_apply_R(SolveWs s, const double* __restrict__ rhs64,
+__global__ __launch_bounds__(64 * 2 * APPLY_PAR) void k_apply_R(SolveWs s, const double* __restrict__ rhs64,
                                                  const float* __restrict__ rhs32, int Kh,
                                                  double* __restrict__ out, float* __restrict__ out32) {
-  __shared__ double sRed[2][2][4][64];
+  __shared__ double sRed[APPLY_PAR - 1][2][2][4][64];
   const int c = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int qj = w & 1, par = w >> 1;
@@ -564,7 +646,7 @@ __global__ __launch_bounds__(256) void k_apply_R(SolveWs s, const double* __rest
   const double* R = s.Lf + (size_t)(s.n_pad + NB) * ld;
   f64x4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
   const int pb = (TRANS ? 0 : c) + par, pe = TRANS ? c + 1 : nblk;
-  for (int p = pb; p < pe; p += 2) {
+  for (int p = pb; p < pe; p += APPLY_PAR) {
     double a[2][8], b[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -586,12 +668,12 @@ __global__ __launch_bounds__(256) void k_apply_R(SolveWs s, const double* __rest
       for (int qi = 0; qi < 2; ++qi)
         if (qi < nqi) acc[qi] = mfma64(a[qi][ks], b[ks], acc[qi]);
   }
-  if (par == 1) {
+  if (par > 0) {
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (qi < nqi) sRed[qi][qj][e][lane] = acc[qi][e];
+        if (qi < nqi) sRed[par - 1][qi][qj][e][lane] = acc[qi][e];
   }
   __syncthreads();
   if (par == 0) {
@@ -601,7 +683,9 @@ __global__ __launch_bounds__(256) void k_apply_R(SolveWs s, const double* __rest
       for (int e = 0; e < 4; ++e) {
         if (qi >= nqi) continue;
         const int h = 16 * qi + acc_row(lane, e), v = NB * c + 16 * qj + x;
-        const double r = acc[qi][e] + sRed[qi][qj][e][lane];
+        double r = acc[qi][e];
+#pragma unroll
+        for (int pp = 0; pp < APPLY_PAR - 1; ++pp) r += sRed[pp][qi][qj][e][lane];  // fixed order
         out[(size_t)v * KHP + h] = r;
         if (out32 && v < n && h < Kh) out32[(size_t)v * Kh + h] = (float)r;
       }
@@ -696,14 +780,14 @@ int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P,
     const int m = s.nblk - 1 - k;
     hipLaunchKernelGGL(k_chol_step, dim3(m + 1, s.nblk + 1), dim3(256), 0, st, s, k);
   }
+  hipLaunchKernelGGL((k_apply_R<false, 0>), dim3(s.nblk), dim3(64 * 2 * APPLY_PAR), 0, st, s, (const double*)nullptr,
+                     (const float*)nullptr, Kh, s.X, P);
 #else
-  {
-    const int ntiles = s.nblk * (s.nblk + 2), cap = chol_resident_workgroups();
-    hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles < cap ? ntiles : cap), dim3(256), 0, st, s);
+  {  // factorisation, R = L^-T, Y^T and P = R Y in one launch
+    const int jobs = s.nblk * (s.nblk + 3), cap = chol_resident_workgroups();
+    hipLaunchKernelGGL(k_chol_tiles, dim3(jobs < cap ? jobs : cap), dim3(256), 0, st, s, Kh, P);
   }
 #endif
-  hipLaunchKernelGGL((k_apply_R<false, 0>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)nullptr,
-                     (const float*)nullptr, Kh, s.X, P);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -715,9 +799,9 @@ int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, siz
   if (ws_bytes < s.bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(ACFM_PROF_SOLVE_BWD, st);
-  hipLaunchKernelGGL((k_apply_R<true, 2>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)nullptr, grad_P, Kh,
+  hipLaunchKernelGGL((k_apply_R<true, 2>), dim3(s.nblk), dim3(64 * 2 * APPLY_PAR), 0, st, s, (const double*)nullptr, grad_P, Kh,
                      s.Z, (float*)nullptr);
-  hipLaunchKernelGGL((k_apply_R<false, 1>), dim3(s.nblk), dim3(256), 0, st, s, (const double*)s.Z,
+  hipLaunchKernelGGL((k_apply_R<false, 1>), dim3(s.nblk), dim3(64 * 2 * APPLY_PAR), 0, st, s, (const double*)s.Z,
                      (const float*)nullptr, Kh, s.Q, (float*)nullptr);
   hipLaunchKernelGGL(k_solve_bwd_lbs, dim3(Kh), dim3(256), 0, st, s, Kh, grad_lbs);
   ACFM_CHECK_LAUNCH();
@@ -725,6 +809,9 @@ int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, siz
 }
 
 #ifdef ACFM_DIAG
+int acfm_debug_potrf_stamps(long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(acfm::g_potrf_stamps), sizeof(long long) * 16) == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
+}
 // diagnostic build only: the 8 clock stamps (10 ns units) of each diagonal job of k_chol_tiles
 int acfm_debug_solve_stamps(const void* ws, int V, long long* out_host, int n) {
   SolveWs s = carve_solve(const_cast<void*>(ws), V);
