@@ -111,7 +111,7 @@ __device__ __forceinline__ f64x4 tile_mma(int lane, f64x4 acc, FA&& fa, FB&& fb)
 }
 
 // The workgroup (4 waves) factorises the SPD tile sC[NB][LDT] (lower part read) and inverts the factor.
-// On return sU[j][0..31] = column j of L (= row j of L^T, zero left of the diagonal) and
+// On return sU[j][r] = L_rj for r >= j (row j of L^T; the entries r < j are unspecified: use potrf_L) and
 // sU[j][32..63] = row j of L^-1; sU ([NB][64], 16 KB) may overlay sC and what follows it.
 // Lanes 0-31 of every wave: lane r owns row r of L; lanes 32-63: lane 32+c owns column c of L^-1
 // (forward substitution).  Both are the recurrence  u_j = (c_j - sum_{p<j} u_p L_jp) / L_jj  with the
@@ -131,6 +131,7 @@ __device__ __forceinline__ double bcast_lane_dyn(double x, int src) {  // src: w
 }
 
 constexpr int PW = 8;  // columns per wave
+__device__ __forceinline__ double potrf_L(const double* sU, int rr, int cc) { return cc <= rr ? sU[cc * 64 + rr] : 0.0; }
 #ifdef ACFM_DIAG
 __device__ long long g_potrf_stamps[16];
 #define POTRF_STAMP(slot) do { if (lane == 0) g_potrf_stamps[4 * w + (slot)] = (long long)wall_clock64(); } while (0)
@@ -158,7 +159,9 @@ __device__ __forceinline__ void potrf32_wg(const double* sC, double* sU, int* sC
   lds_vint* count = (lds_vint*)sCount;
   lds_vdouble* U = (lds_vdouble*)sU;
   // ---- the pivots of the earlier panels, as they appear: every poll reads the counter together with the row
-  // of the next pivot, so a published pivot costs one LDS round trip, not two
+  // of the next pivot, so a published pivot costs one LDS round trip, not two.  (Requesting the row after it as
+  // well, so that a follower with a backlog catches up faster, measured 4 us SLOWER over the 21 tiles: the
+  // followers' extra LDS traffic delays the leader.)
   for (int done = 0; done < PW * w;) {
     const int avail = *count;
     const double u = U[done * 64 + lane];
@@ -170,15 +173,17 @@ __device__ __forceinline__ void potrf32_wg(const double* sC, double* sU, int* sC
     for (int q = 0; q < PW; ++q) c[q] -= u * l[q];
     ++done;
   }
-  // ---- this wave's panel
+  // ---- this wave's panel.  Nothing but the chain and the panel's own updates in the loop: a lone wave issues an
+  // instruction every 2-4 ns, so rows above the diagonal are stored as they come (the readers mask them) and the
+  // pivot check is made afterwards from the stored diagonal.
   POTRF_STAMP(1);
-  bool bad = false;
+  lds_vdouble* Uw = U + PW * w * 64 + lane;
+  lds_vint* cw = count;
 #pragma unroll
   for (int jj = 0; jj < PW; ++jj) {
     const int j = PW * w + jj;
     const double sum = c[jj];
     const double piv = bcast_lane_dyn(sum, j);
-    bad = bad || !(piv > 0.0);
     // y = piv^-1/2: y0 = rsq, e = 1/2 - piv/2 y0^2, y = y0 (1 + e (1 + 3/2 e)) + O(e^3); the lane's value is
     // sum * y (lane j: piv * y = the diagonal entry)
     const double y0 = __builtin_amdgcn_rsq(piv);
@@ -188,12 +193,18 @@ __device__ __forceinline__ void potrf32_wg(const double* sC, double* sU, int* sC
     const double v = s0 + s0 * h;
 #pragma unroll
     for (int q = jj + 1; q < PW; ++q) c[q] -= v * bcast_lane_dyn(v, PW * w + q);
-    U[j * 64 + lane] = (low && r < j) ? 0.0 : v;
-    *count = j + 1;  // every lane stores the same word: LDS executes a wave's accesses in order
+    Uw[jj * 64] = v;
+    *cw = j + 1;  // every lane stores the same word: LDS executes a wave's accesses in order
   }
   POTRF_STAMP(2);
-  if (bad && lane == 0) atomicMax(info, base_index + 1);
   __syncthreads();
+  if (w == 0) {
+    // lane j < 32: the diagonal entry piv_j^(1/2) is positive and finite unless pivot j (or one before it) was not
+    // positive
+    const double d = sU[r * 64 + r];
+    const unsigned long long badmask = __ballot(low && !(d > 0.0 && d < 1.0e300));
+    if (badmask && lane == 0) atomicMax(info, base_index + __ffsll((long long)badmask));
+  }
   POTRF_STAMP(3);
 }
 
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256) void k_chol_first(SolveWs s) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-    s.Lf[(size_t)rr * s.ld + cc] = sBuf[cc * 64 + rr];
+    s.Lf[(size_t)rr * s.ld + cc] = potrf_L(sBuf, rr, cc);
     s.Linv[rr * NB + cc] = sBuf[rr * 64 + 32 + cc];
   }
 }
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = sU[cc * 64 + rr];
+      s.Lf[(size_t)(NB * i + rr) * s.ld + NB * i + cc] = potrf_L(sU, rr, cc);
       invn[rr * NB + cc] = sU[rr * 64 + 32 + cc];
     }
   }
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s, int Kh, float* __
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = t + 256 * e, rr = idx >> 5, cc = idx & 31;
-        st_word(s.Lf + (size_t)(NB * i + rr) * ld + NB * i + cc, sU[cc * 64 + rr]);
+        st_word(s.Lf + (size_t)(NB * i + rr) * ld + NB * i + cc, potrf_L(sU, rr, cc));
       }
       CHOL_STAMP(5);
     }
