@@ -748,6 +748,12 @@ using namespace acfm;
 #define ACFM_CHOL_STEPS 0  // 1: the factorisation as one launch per tile column (the round-1 path, kept for A/B runs)
 #endif
 
+// One workgroup per CU: a second one on the CU of a diagonal job, even one that only waits, slows that job's
+// serial chain (measured on the 642-vertex solve: 186 us with two per CU, 175 with one; 176 / 200 / 296 us with
+// 192 / 128 / 64 workgroups in all).
+#ifndef CHOL_PER_CU
+#define CHOL_PER_CU 1
+#endif
 // workgroups of k_chol_tiles the device holds at once; only a grid size (the ticket makes any number correct)
 static int chol_resident_workgroups() {
   static std::atomic<int> cached[64];
@@ -758,7 +764,7 @@ static int chol_resident_workgroups() {
   int cus = 0, per = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_chol_tiles, 256, 0) != hipSuccess || per <= 0) per = 1;
-  v = cus * (per > 4 ? 4 : per);
+  v = cus * (per > CHOL_PER_CU ? CHOL_PER_CU : per);
   cached[dev].store(v, std::memory_order_relaxed);
   return v;
 }
