@@ -5,23 +5,28 @@
 // the current mean shape, no grad) for every frame and calls torch.cholesky + cholesky_solve
 // (multiframe/main.py:586-609).  Both the mean shape and lbs are learned, so M changes every
 // optimiser step: one V x V SPD factorisation per step is part of the training hot path.  This
-// file does it once per step for all frames (deform.py) as a right-looking blocked Cholesky
-// with 32 x 32 tiles, fp64 throughout (v_mfma_f64_16x16x4_f64):
+// file does it once per step for all frames (deform.py) as a blocked Cholesky with 32 x 32 tiles,
+// fp64 throughout (v_mfma_f64_16x16x4_f64), in four launches:
 //
+//   k_solve_prepare   sentinel fill of the tiles the factorisation publishes, status / ticket reset
 //   k_solve_softmax   A = softmax over vertices of each handle's logits (fp64), one WG per handle
 //   k_solve_gram_rows W = L^T L + A^T A, one WG per row; only the non-zeros of L's column are
 //                     visited (the cotangent Laplacian has ~7 per column), fixed summation order
-//   k_chol_step(k)    one launch per tile column k:  L_ik = W_ik L_kk^-T for the tiles below the
-//                     diagonal (recomputed inside every consumer instead of a second launch),
-//                     W_ij -= L_ik L_jk^T on the trailing tiles, and the WG that owns the next
-//                     diagonal tile factorises it (one wave, registers only) and inverts the factor.
-//                     Two more groups of tile rows ride along: the right-hand sides A (so
-//                     Y^T = A L^-T is free) and an identity (so R = L^-T is free): both only add
-//                     independent tiles to launches whose critical path is the diagonal tile.
-//   k_apply_R         P = R Y: with R explicit the substitutions are tile GEMMs, one WG per
-//                     32 vertices, no serial chain
-// backward (dP -> dlbs):  Q = M^-1 dP = R (R^T dP)  (k_apply_R twice),
+//   k_chol_tiles      ONE launch for the factorisation and both substitutions: every tile of the
+//                     factor is a job (acc = W_ij - sum_k L_ik L_jk^T as the L tiles appear, then
+//                     L_ij = acc L_jj^-T; the diagonal job factorises and inverts its tile with the
+//                     four waves of the workgroup, potrf32_wg).  Two more groups of tile rows are
+//                     jobs like the others: the right-hand sides A (so Y^T = A L^-T is free) and an
+//                     identity (so R = L^-T is free); the last jobs form P = R Y.  Jobs are dealt by
+//                     a ticket in an order in which a job only waits for lower tickets, and tiles are
+//                     handed from job to job as self-validating 8-byte words (see k_chol_tiles).
+// backward (dP -> dlbs):  Q = M^-1 dP = R (R^T dP)  (k_apply_R twice: with R explicit the
+//   substitutions are tile GEMMs, one WG of 16 waves per 32 vertices, no serial chain),
 //   dA = Q^T - (A Q) P^T - (A P) Q^T,   dlbs = softmax backward per handle     (k_solve_bwd_lbs)
+//
+// -DACFM_CHOL_STEPS=1 (make VARIANT=steps EXTRA=-DACFM_CHOL_STEPS=1) builds the round-1 schedule instead
+// -- one launch per tile column (k_chol_first, k_chol_step x nblk, k_apply_R) -- for A/B runs; both give
+// bit-identical results (same operations in the same order).
 //
 // Storage: (2 nblk + 1) x nblk tiles, row-major, ld = n_pad = 32 nblk; tile rows [0, nblk) the
 // matrix, tile row nblk the right-hand sides (row h = handle h), tile rows (nblk, 2 nblk] the

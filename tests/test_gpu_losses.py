@@ -225,6 +225,56 @@ def test_deform_solve_native(meshes):
         ops.deform_solve(torch.zeros(40, 40, device=d), torch.full((40, 2), float("nan"), device=d), check=True)
 
 
+def test_deform_solve_single_launch(meshes):
+    """The factorisation as ONE launch of ticketed tile jobs (k_chol_tiles, csrc/acfm_solve.hip): more jobs than the
+    device holds at once (V = 2562: 6 804 jobs on 256 resident workgroups, so the ticket order is what keeps it
+    moving), bit-identical repeats (fixed summation order whatever the order the jobs run in), other work in flight
+    on a second stream, and replay from a hipGraph (the sentinel fill is part of the captured sequence)."""
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    v2, f2 = O.subdivide(v, f)
+    v2, f2 = np.asarray(v2, dtype=np.float32), np.asarray(f2)
+    assert v2.shape[0] == 2562
+    L = O.laplacian_cot(torch.from_numpy(v2).double(), torch.from_numpy(f2)).float()
+    logits = torch.tensor(fps_lbs_logits(v2, 12))
+    lg = logits.clone().to(d).requires_grad_(True)
+    P = ops.deform_solve(L.to(d), lg, check=True)
+    P.square().sum().backward()
+    l64 = logits.double().requires_grad_(True)
+    A = torch.softmax(l64, dim=0).t()
+    M = L.double().t() @ L.double() + A.t() @ A
+    ref = torch.cholesky_solve(A.t(), torch.linalg.cholesky(M))
+    ref.square().sum().backward()
+    assert float((P.detach().cpu().double() - ref.detach()).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert float((lg.grad.cpu().double() - l64.grad).abs().max()) < 1e-4 * float(l64.grad.abs().max())
+    # repeats, with a memory-bound kernel running beside them on another stream
+    vh, fh = torch.from_numpy(v), torch.from_numpy(f)
+    Lh = O.laplacian_cot(vh.double(), fh).float().to(d)
+    lh = torch.tensor(fps_lbs_logits(v, 15), device=d)
+    first = ops.deform_solve(Lh, lh).clone()
+    side, big = torch.cuda.Stream(), torch.empty(64 << 20, device=d)
+    torch.cuda.synchronize()
+    for _ in range(10):
+        with torch.cuda.stream(side):
+            big.add_(1.0)
+        assert torch.equal(ops.deform_solve(Lh, lh), first)
+    torch.cuda.synchronize()
+    # graph replay
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = ops.deform_solve(Lh, lh)  # warm-up on the capture stream
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = ops.deform_solve(Lh, lh)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+
+
 def test_mesh_priors_hip(meshes):
     """a9 / a14 / a15 on the GPU: cot Laplacian, Laplacian smoothing (cot + uniform) and edge rigidity
     through the reference-shaped API, against the reference's golden outputs and the oracle."""
