@@ -39,6 +39,11 @@ struct ProfScope {
   ~ProfScope() { prof_end(st); }
 };
 
+#ifndef ACFM_CTILE
+#define ACFM_CTILE 16
+#endif
+constexpr int CTILE = ACFM_CTILE;  // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
+
 // Per-face record of the raster workspace (k_setup writes it, the binning of the raster kernels reads it).
 // Two cache lines: the first is all the backward walk needs; the second holds what is constant per FACE in the
 // exact per-pixel test -- the three edge vectors, their squared lengths and refined reciprocals (the operands
@@ -73,7 +78,7 @@ struct RasterWs {
   uint8_t* fvis;   // [N,F] 1 = the face is the nearest one at some pixel of the last texture render on this workspace
   int* n_work;     // [8] per XCD group: entries of its order that have work (the flagged-empty ones follow them)
   int split_slots; // heaviest blocks per XCD group that may be rendered by four workgroups each (raster kernels)
-  unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every 32x32-pixel coarse tile (words = ceil(F/64) u64)
+  unsigned* cmask; // [N,ctiles^2,2*words] face bitmask of every CTILE x CTILE-pixel coarse tile (words = ceil(F/64) u64)
   float4* lpart;   // [N,blocks^2,4] fused render+loss: per 8x8 block (x 4 split roles) partial sums of the silhouette
                    // loss terms, written by the raster kernel, summed in fixed order by k_sil_loss_finish
   float* lpart2;   // [N,64,5] second-stage partial sums of the same
@@ -130,7 +135,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
   w.n_work = (int*)(p + o);     o += align256(sizeof(int) * 8);
   w.fvis = (uint8_t*)(p + o);   o += align256((size_t)N * F);
-  const size_t ct = (size_t)((H + 31) / 32) * ((H + 31) / 32), words = ((size_t)F + 63) / 64;
+  const size_t ct = (size_t)((H + CTILE - 1) / CTILE) * ((H + CTILE - 1) / CTILE), words = ((size_t)F + 63) / 64;
   w.cmask = (unsigned*)(p + o); o += align256(sizeof(unsigned) * 2 * (size_t)N * ct * words);
   w.lpart = (float4*)(p + o);   o += align256(sizeof(float4) * 4 * (size_t)N * tt);
   w.lpart2 = (float*)(p + o);   o += align256(sizeof(float) * 5 * 64 * (size_t)N);

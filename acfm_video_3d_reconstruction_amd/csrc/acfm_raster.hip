@@ -8,7 +8,7 @@
 // Design:
 //   * k_setup: four workgroups per mesh project the V vertices into LDS (weak-perspective
 //     camera, y flip, view transform) and write one 64-byte record per face (blur-expanded box,
-//     vertices, depths), the face bitmask of every 32x32 coarse tile and a cost count per 8x8
+//     vertices, depths), the face bitmask of every 16x16 coarse tile and a cost count per 8x8
 //     block; k_order sorts every XCD group's (mesh, block) entries heavy-first (counting sort,
 //     no atomics) and puts the blocks no face box comes near at the end.
 //   * k_raster_fwd / k_sil_bwd share one skeleton: a ONE-WAVE workgroup owns an 8x8 pixel
@@ -68,7 +68,6 @@ constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes ne
 constexpr int ENTRY_SPLIT = 1 << 29;   // order entry flag: a heavy block, rendered by four workgroups (one per 4x4 pixels)
 constexpr int ENTRY_FLAGS = ENTRY_EMPTY | ENTRY_SPLIT;
 constexpr int SPLIT_MAX_CLASS = 2;     // ... if their cost class is at most this (>= 80 face boxes)
-constexpr int CTILE = 32;     // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
 typedef unsigned short fl_t;  // face ids of one mesh (F <= ACFM_MAX_FACES = 65535)
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     for (int i = tid; i < tt_; i += TPB) s_cnt[i] = 0;
   const int q = setup_slice_faces(F);
   const int f_lo = slice * q, f_hi = min(F, f_lo + q);
-  // coarse face masks: bit f of row (cty, ctx) <=> the box of face f may touch that 32x32 tile
+  // coarse face masks: bit f of row (cty, ctx) <=> the box of face f may touch that CTILE x CTILE tile
   const int ctiles_ = (H + CTILE - 1) / CTILE, mwords = 2 * ((F + 63) / 64);  // u32 words per row
   const int rows = ctiles_ * ctiles_;
   const int w_lo = f_lo >> 5, w_n = max(0, min(mwords, (f_lo + q) >> 5) - w_lo);  // this slice's words of a row
@@ -685,7 +684,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
 }
 
 // Bins the faces of mesh t.n against the wave's 8x8 block and calls walk(count) whenever the LDS
-// list is complete or could overflow.  The faces come from the bitmask of the block's 32x32
+// list is complete or could overflow.  The faces come from the bitmask of the block's 16x16
 // coarse tile (k_setup): lane i expands mask word i into the wave's face-id list (ascending), then
 // 64 ids per round lane i tests face i's box; survivors are compacted with one ballot, face
 // order kept.  No barriers: the workgroup is one wave.
