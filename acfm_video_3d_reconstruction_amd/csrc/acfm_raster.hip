@@ -884,9 +884,17 @@ typedef _Float16 half_t;
 __device__ __forceinline__ float ld_real(const void* p, size_t i, int h16) {
   return h16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
 }
+#ifndef ACFM_OUT_NT
+#define ACFM_OUT_NT 0
+#endif
 __device__ __forceinline__ void st_real(void* p, size_t i, float v, int h16) {
+#if ACFM_OUT_NT
+  if (h16) __builtin_nontemporal_store((half_t)v, reinterpret_cast<half_t*>(p) + i);
+  else __builtin_nontemporal_store(v, reinterpret_cast<float*>(p) + i);
+#else
   if (h16) reinterpret_cast<half_t*>(p)[i] = (half_t)v;
   else reinterpret_cast<float*>(p)[i] = v;
+#endif
 }
 __device__ __forceinline__ float4 ld4_real(const void* p, size_t i4, int h16) {   // elements 4 i4 .. 4 i4 + 3 (aligned)
   if (!h16) return reinterpret_cast<const float4*>(p)[i4];
@@ -895,8 +903,13 @@ __device__ __forceinline__ float4 ld4_real(const void* p, size_t i4, int h16) { 
   return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
 __device__ __forceinline__ void st_face(void* p, size_t i, long long id, int h16) {   // nearest-face plane
+#if ACFM_OUT_NT
+  if (h16) __builtin_nontemporal_store((int32_t)id, reinterpret_cast<int32_t*>(p) + i);
+  else __builtin_nontemporal_store((int64_t)id, reinterpret_cast<int64_t*>(p) + i);
+#else
   if (h16) reinterpret_cast<int32_t*>(p)[i] = (int32_t)id;
   else reinterpret_cast<int64_t*>(p)[i] = (int64_t)id;
+#endif
 }
 
 struct FwdOut {
@@ -1271,6 +1284,18 @@ __device__ __forceinline__ void pix_lists_walk(const RasterWs& ws, const Tile& t
 // Constant outputs of a flagged-empty 8x8 block (no face box comes near it): exactly what
 // fwd_block leaves for a block without candidates.  Lane i owns pixel (i / 8, i % 8) of the block;
 // the K ids of the soft kernel go out as 16-byte pieces in image order (8 rows of 64 K bytes).
+// The K-slot pix_to_face stores (160 B per pixel at K = 20: whole lines, never read by this library) go out
+// non-temporal: -7 us on the K = 20 forward.  The 4-byte-per-pixel planes must NOT (ACFM_OUT_NT=1 measured 75 ->
+// 123 us on the texture forward): a block row of such a plane is a 32-byte fragment and the four fragments of a
+// line meet in L2.
+#ifndef ACFM_P2F_NT
+#define ACFM_P2F_NT 1
+#endif
+#if ACFM_P2F_NT
+#define P2F_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define P2F_STORE(ptr, val) (*(ptr) = (val))
+#endif
 template <int K, bool TEX>
 __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by, int bx, int H, int lane) {
   const int yi = by + (lane >> 3), xi = bx + (lane & 7);
@@ -1309,7 +1334,7 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
       const int c = i * 64 + lane;             // piece index: 8 rows x (8 pixels x CH pieces)
       const int r = c / (8 * CH), off = c % (8 * CH);
       if (by + r < H && bx + off / CH < H)
-        reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off] = v;
+        P2F_STORE(&reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off], v);
     }
   }
 }
@@ -1608,7 +1633,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         const int c = i * 64 + t.lane;             // piece index: 8 rows x (8 pixels x CH pieces)
         const int r = c / (8 * CH), off = c % (8 * CH);
         if (by + r < H && bx + off / CH < H)
-          reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off] = so[c];
+          P2F_STORE(&reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + (((size_t)n * H + by + r) * H + bx) * K)[off], so[c]);
       }
     } else if (out_valid) {
       ll2* o2 = reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + t.pix * K);

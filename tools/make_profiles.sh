@@ -6,11 +6,7 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 2
 o=gpurun_out/profiles_$tag; rm -rf $o; mkdir -p $o
 B="python3 bench.py --steps 20 --warmup 5 --headline-only --eager"
-# 1. the bench line (default flags) and the rocprof kernel summary of the same program
-python3 bench.py > $o/${tag}_bench.json 2> $o/bench.err || { tail -5 $o/bench.err; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -- python3 bench.py --steps 20 --warmup 5 --headline-only > $o/stats.log 2>&1 || exit 1
-cp "$(ls -t $(find $o/stats -name '*kernel_stats.csv') | head -1)" $o/${tag}_bench_kernel_stats.csv
-# 2. PMC passes ON bench.py itself (eager launches so that every kernel is a dispatch of its own), one counter group per pass
+# 1. PMC passes ON bench.py itself (eager launches so that every kernel is a dispatch of its own), one counter group per pass
 tools/pmc.sh $o/pmc_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- $B > $o/${tag}_pmc_sq.txt 2>&1 || exit 1
 tools/pmc.sh $o/pmc_sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $B >> $o/${tag}_pmc_sq.txt 2>&1 || exit 1
 # where the issue stalls go: LDS / scalar / vector-memory shares of the instruction stream
@@ -18,9 +14,15 @@ tools/pmc.sh $o/pmc_sq3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA S
 tools/pmc.sh $o/pmc_f FETCH_SIZE -- $B > $o/${tag}_pmc_hbm.txt 2>&1 || exit 1
 tools/pmc.sh $o/pmc_w WRITE_SIZE -- $B >> $o/${tag}_pmc_hbm.txt 2>&1 || exit 1
 python3 tools/pmc_traffic.py --frames 64 --img 256 --mesh bird --storage f32 --command "$B" $o/${tag}_pmc_hbm.txt $o/${tag}_pmc_sq.txt > $o/${tag}_pmc_traffic.json
+cp $o/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json   # the bench line below cites this round's counters
+# 2. the bench line (default flags) and the rocprof kernel summary of the same program
+python3 bench.py > $o/${tag}_bench.json 2> $o/bench.err || { tail -5 $o/bench.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -- python3 bench.py --steps 20 --warmup 5 --headline-only > $o/stats.log 2>&1 || exit 1
+cp "$(ls -t $(find $o/stats -name '*kernel_stats.csv') | head -1)" $o/${tag}_bench_kernel_stats.csv
 # 3. config 5 (one GPU's share): its own bench line
 python3 bench.py --config 5 > $o/${tag}_bench_config5.json 2> $o/bench5.err || { tail -5 $o/bench5.err; exit 1; }
 # 4. the callers either side of the render path
 (python3 tools/step_bench.py; python3 tools/step_bench.py --graph; python3 tools/solve_bench.py; python3 tools/refine_bench.py) > $o/${tag}_step_solve_refine.txt 2>&1
 build_ub/valu_rates > $o/${tag}_valu_rates.txt 2>&1
+[ -x tools/ubench/f64_chain ] && tools/ubench/f64_chain > $o/${tag}_f64_chain.txt 2>&1
 ls -la $o
