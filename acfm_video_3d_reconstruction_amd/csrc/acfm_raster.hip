@@ -703,10 +703,17 @@ __device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
   return x;
 }
 
+// ACFM_MBOX_TEST: the mesh-box early-out in front of the mask loads.  It looks redundant beside k_order's empty flag,
+// but the flag comes from counts per 16x16 pixels: without the test the K = 20 kernels measured 6-7 us slower each
+// (blocks next to the mesh that bin a mask row to find nothing), the K = 1 kernel 2 us faster.
+#ifndef ACFM_MBOX_TEST
+#define ACFM_MBOX_TEST 1
+#endif
 template <class LT, class Walk>
 __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, int F, int H, LT& L,
                                              fl_t* s_fl /* [FLCAP] */, float box_shrink, Walk&& walk) {
   if (t.empty) return;  // flagged by k_order: no face box near this block
+#if ACFM_MBOX_TEST
   float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
 #pragma unroll
   for (int i = 1; i < SETUP_SLICES; ++i) {
@@ -714,6 +721,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
     mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
   }
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
+#endif
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
   const int cty = (t.yi & ~7) / CTILE, ctx = (t.xi & ~7) / CTILE;
