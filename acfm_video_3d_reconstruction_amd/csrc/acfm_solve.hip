@@ -708,32 +708,39 @@ __global__ __launch_bounds__(64 * 2 * APPLY_PAR) void k_apply_R(SolveWs s, const
   }
 }
 
-// ---- dlbs from Q = M^-1 dP; grid = Kh, one handle (one softmax column) per WG -------------------
-__global__ __launch_bounds__(256) void k_solve_bwd_lbs(SolveWs s, int Kh, float* __restrict__ grad_lbs) {
-  __shared__ double scratch[256];
+// ---- dlbs from Q = M^-1 dP; grid = Kh, one handle (one softmax column) per WG of 16 waves --------------------
+// A handful of flops per vertex behind long load latencies: 1024 threads keep every loop to a few rounds of
+// independent loads (256 threads: 80 dependent rounds in the (A Q), (A P) sums alone, 33 us; now ~10 us).
+constexpr int BWD_T = 1024;
+__global__ __launch_bounds__(BWD_T) void k_solve_bwd_lbs(SolveWs s, int Kh, float* __restrict__ grad_lbs) {
+  __shared__ double scratch[BWD_T], scratch2[BWD_T];
   __shared__ double sAQ[KHP], sAP[KHP];
   const int h = blockIdx.x, t = threadIdx.x;
   const double* a_row = s.A64 + (size_t)h * s.n_pad;
-  {  // (A Q)[h][h'], (A P)[h][h']: 8 partial sums per output
+  {  // (A Q)[h][h'], (A P)[h][h']: 32 partial sums per output, two independent chains each
     const int hp = t & 31, part = t >> 5;
-    double aq = 0.0, ap = 0.0;
-    for (int v = part; v < s.n; v += 8) {
-      const double a = a_row[v];
-      aq += a * s.Q[(size_t)v * KHP + hp];
-      ap += a * s.X[(size_t)v * KHP + hp];
+    double aq0 = 0.0, aq1 = 0.0, ap0 = 0.0, ap1 = 0.0;
+    for (int v = part; v < s.n; v += 64) {
+      const int v1 = v + 32;
+      const double a0 = a_row[v], a1 = v1 < s.n ? a_row[v1] : 0.0;
+      const size_t o0 = (size_t)v * KHP + hp, o1 = (size_t)(v1 < s.n ? v1 : v) * KHP + hp;
+      aq0 += a0 * s.Q[o0]; ap0 += a0 * s.X[o0];
+      aq1 += a1 * s.Q[o1]; ap1 += a1 * s.X[o1];
     }
-    scratch[t] = aq;
+    scratch[t] = aq0 + aq1;
+    scratch2[t] = ap0 + ap1;
     __syncthreads();
-    if (t < 32) { double z = 0.0; for (int q = 0; q < 8; ++q) z += scratch[t + 32 * q]; sAQ[t] = z; }
-    __syncthreads();
-    scratch[t] = ap;
-    __syncthreads();
-    if (t < 32) { double z = 0.0; for (int q = 0; q < 8; ++q) z += scratch[t + 32 * q]; sAP[t] = z; }
+    if (t < 64) {  // fixed order over the 32 parts
+      const double* src = t < 32 ? scratch : scratch2;
+      double z = 0.0;
+      for (int q = 0; q < 32; ++q) z += src[(t & 31) + 32 * q];
+      (t < 32 ? sAQ : sAP)[t & 31] = z;
+    }
     __syncthreads();
   }
   double* gA = s.W + (size_t)(s.n_pad + h) * s.ld;  // the right-hand-side row of W is free by now
   double dot = 0.0;
-  for (int v = t; v < s.n; v += 256) {
+  for (int v = t; v < s.n; v += BWD_T) {
     const double* q = s.Q + (size_t)v * KHP;
     const double* p = s.X + (size_t)v * KHP;
     double g = q[h];
@@ -741,8 +748,14 @@ __global__ __launch_bounds__(256) void k_solve_bwd_lbs(SolveWs s, int Kh, float*
     gA[v] = g;
     dot += a_row[v] * g;
   }
-  dot = block_reduce(dot, scratch, [](double a, double b) { return a + b; });
-  for (int v = t; v < s.n; v += 256) grad_lbs[(size_t)v * Kh + h] = (float)(a_row[v] * (gA[v] - dot));
+  scratch[t] = dot;
+  __syncthreads();
+  for (int w = BWD_T / 2; w > 0; w >>= 1) {
+    if (t < w) scratch[t] += scratch[t + w];
+    __syncthreads();
+  }
+  dot = scratch[0];
+  for (int v = t; v < s.n; v += BWD_T) grad_lbs[(size_t)v * Kh + h] = (float)(a_row[v] * (gA[v] - dot));
 }
 
 }  // namespace acfm
@@ -825,7 +838,7 @@ int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, siz
                      s.Z, (float*)nullptr);
   hipLaunchKernelGGL((k_apply_R<false, 1>), dim3(s.nblk), dim3(64 * 2 * APPLY_PAR), 0, st, s, (const double*)s.Z,
                      (const float*)nullptr, Kh, s.Q, (float*)nullptr);
-  hipLaunchKernelGGL(k_solve_bwd_lbs, dim3(Kh), dim3(256), 0, st, s, Kh, grad_lbs);
+  hipLaunchKernelGGL(k_solve_bwd_lbs, dim3(Kh), dim3(BWD_T), 0, st, s, Kh, grad_lbs);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
