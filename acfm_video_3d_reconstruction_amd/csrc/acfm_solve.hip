@@ -214,8 +214,15 @@ __device__ __forceinline__ void potrf32_wg(const double* sC, double* sU, int* sC
 }
 
 // ---- A = softmax(lbs[:, h]) over the vertices, fp64; grid = 32 (rows >= Kh are zero) ----------
+// grid = 32, or 32 + solve_prepare_blocks: the workgroups beyond the 32 handles fill the sentinels of the tile launch
+// (neither half depends on the other, both precede the rows of W: one launch instead of two)
+__device__ __forceinline__ void solve_prepare_block(const SolveWs& s, int b_in);
 __global__ __launch_bounds__(256) void k_solve_softmax(const float* __restrict__ lbs, SolveWs s, int Kh) {
   __shared__ double scratch[256];
+  if (blockIdx.x >= KHP) {
+    solve_prepare_block(s, (int)blockIdx.x - KHP);
+    return;
+  }
   const int h = blockIdx.x, t = threadIdx.x;
   double* rowW = s.W + (size_t)(s.n_pad + h) * s.ld;
   double* rowA = s.A64 + (size_t)h * s.n_pad;
@@ -242,7 +249,13 @@ __global__ __launch_bounds__(256) void k_solve_softmax(const float* __restrict__
 // W[i][c] = sum_h A[h][i] A[h][c] + sum_r L[r][i] L[r][c]: the WG scans column i of L, keeps the
 // non-zero (r, L[r][i]) in ascending r, and adds those rows of L; each output element is summed
 // by one thread in a fixed order (h ascending, then r ascending).
-constexpr int GRAM_CPT = 4;  // columns per thread and pass
+// The work is a few hundred flops per thread behind load latencies, so loads travel in batches: the column scan
+// asks for GRAM_RPT rows per thread at once (1024 rows per round), and the rows of L that are added are fetched
+// GRAM_EB at a time before their terms are summed in order.
+constexpr int GRAM_CPT = 4;   // columns per thread and pass
+constexpr int GRAM_RPT = 4;   // rows of the column scan per thread and round
+constexpr int GRAM_EB = 8;    // rows of L in flight while summing
+constexpr int GRAM_HB = 8;    // handles of A in flight while summing
 __global__ __launch_bounds__(256) void k_solve_gram_rows(const float* __restrict__ L, SolveWs s, int Kh) {
   const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int n = s.n;
@@ -251,9 +264,9 @@ __global__ __launch_bounds__(256) void k_solve_gram_rows(const float* __restrict
     for (int c = t; c < s.n_pad; c += 256) wrow[c] = (c == i) ? 1.0 : 0.0;
     return;
   }
-  __shared__ int s_r[256];
-  __shared__ double s_v[256];
-  __shared__ int s_wcnt[4];
+  __shared__ int s_r[256 * GRAM_RPT];
+  __shared__ double s_v[256 * GRAM_RPT];
+  __shared__ int s_wcnt[GRAM_RPT][4];
   for (int cb = 0; cb < s.n_pad; cb += 256 * GRAM_CPT) {
     double acc[GRAM_CPT];
     int col[GRAM_CPT];
@@ -261,28 +274,71 @@ __global__ __launch_bounds__(256) void k_solve_gram_rows(const float* __restrict
     for (int q = 0; q < GRAM_CPT; ++q) {
       col[q] = cb + t + 256 * q;
       acc[q] = 0.0;
-      if (col[q] < n)
-        for (int h = 0; h < Kh; ++h)
-          acc[q] += s.A64[(size_t)h * s.n_pad + i] * s.A64[(size_t)h * s.n_pad + col[q]];
     }
-    for (int r0 = 0; r0 < n; r0 += 256) {
-      const int r = r0 + t;
-      const float val = r < n ? L[(size_t)r * n + i] : 0.f;
-      const bool nz = val != 0.f;
-      const unsigned long long bal = __ballot(nz);
-      if (lane == 0) s_wcnt[w] = __popcll(bal);
-      __syncthreads();
-      int off = __popcll(bal & ((1ull << lane) - 1ull));
-      for (int ww = 0; ww < w; ++ww) off += s_wcnt[ww];
-      const int cnt = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      if (nz) { s_r[off] = r; s_v[off] = (double)val; }
-      __syncthreads();
-      for (int e = 0; e < cnt; ++e) {
-        const float* lrow = L + (size_t)s_r[e] * n;
-        const double lv = s_v[e];
+    // the first round of the column scan is asked for before the A^T A terms are summed: its latency hides behind them
+    float val[GRAM_RPT];
+#pragma unroll
+    for (int k = 0; k < GRAM_RPT; ++k) {
+      const int r = 256 * k + t;
+      val[k] = r < n ? L[(size_t)r * n + i] : 0.f;
+    }
+    for (int h0 = 0; h0 < Kh; h0 += GRAM_HB) {  // GRAM_HB handles' loads in flight, summed in order
+      double ai[GRAM_HB], ac[GRAM_HB][GRAM_CPT];
+#pragma unroll
+      for (int e = 0; e < GRAM_HB; ++e) {
+        const int h = h0 + e < Kh ? h0 + e : h0;
+        ai[e] = s.A64[(size_t)h * s.n_pad + i];
+#pragma unroll
+        for (int q = 0; q < GRAM_CPT; ++q) ac[e][q] = col[q] < n ? s.A64[(size_t)h * s.n_pad + col[q]] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < GRAM_HB; ++e) {
+        if (h0 + e >= Kh) break;
 #pragma unroll
         for (int q = 0; q < GRAM_CPT; ++q)
-          if (col[q] < n) acc[q] += lv * (double)lrow[col[q]];
+          if (col[q] < n) acc[q] += ai[e] * ac[e][q];
+      }
+    }
+    for (int r0 = 0; r0 < n; r0 += 256 * GRAM_RPT) {
+      if (r0 > 0) {
+#pragma unroll
+        for (int k = 0; k < GRAM_RPT; ++k) {
+          const int r = r0 + 256 * k + t;
+          val[k] = r < n ? L[(size_t)r * n + i] : 0.f;
+        }
+      }
+      unsigned long long bal[GRAM_RPT];
+#pragma unroll
+      for (int k = 0; k < GRAM_RPT; ++k) {
+        bal[k] = __ballot(val[k] != 0.f);
+        if (lane == 0) s_wcnt[k][w] = __popcll(bal[k]);
+      }
+      __syncthreads();
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < GRAM_RPT; ++k) {  // ascending r: sub-chunk k, then wave, then lane
+        int off = cnt + __popcll(bal[k] & ((1ull << lane) - 1ull));
+        for (int ww = 0; ww < w; ++ww) off += s_wcnt[k][ww];
+        if (val[k] != 0.f) { s_r[off] = r0 + 256 * k + t; s_v[off] = (double)val[k]; }
+        cnt += s_wcnt[k][0] + s_wcnt[k][1] + s_wcnt[k][2] + s_wcnt[k][3];
+      }
+      __syncthreads();
+      for (int e0 = 0; e0 < cnt; e0 += GRAM_EB) {
+        float lv[GRAM_EB][GRAM_CPT];
+#pragma unroll
+        for (int e = 0; e < GRAM_EB; ++e) {
+          const float* lrow = L + (size_t)s_r[e0 + e < cnt ? e0 + e : e0] * n;
+#pragma unroll
+          for (int q = 0; q < GRAM_CPT; ++q) lv[e][q] = col[q] < n ? lrow[col[q]] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < GRAM_EB; ++e) {
+          if (e0 + e >= cnt) break;
+          const double v = s_v[e0 + e];
+#pragma unroll
+          for (int q = 0; q < GRAM_CPT; ++q)
+            if (col[q] < n) acc[q] += v * (double)lv[e][q];
+        }
       }
       __syncthreads();
     }
@@ -438,9 +494,9 @@ __device__ __forceinline__ bool gate(const double* word, int& budget) {
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_solve_prepare(SolveWs s) {
+__device__ __forceinline__ void solve_prepare_block(const SolveWs& s, int b_in) {
   // sentinel into every tile k_chol_tiles publishes (and the diagonal inverses); grid = (2 nblk + 1) nblk + nblk
-  const int nb = s.nblk, tiles = (2 * nb + 1) * nb, b = blockIdx.x, t = threadIdx.x;
+  const int nb = s.nblk, tiles = (2 * nb + 1) * nb, b = b_in, t = threadIdx.x;
   ulonglong2 ones = {CHOL_SENTINEL, CHOL_SENTINEL};
   if (b >= tiles) {
     ulonglong2* d = reinterpret_cast<ulonglong2*>(s.Linv + (size_t)(b - tiles) * NB * NB);
@@ -804,10 +860,10 @@ int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P,
 #if ACFM_CHOL_STEPS
   if (zero_async(s.W + (size_t)(s.n_pad + NB) * s.ld, sizeof(double) * (size_t)s.n_pad * s.ld, st) != ACFM_OK)
     return ACFM_E_LAUNCH;
-#else
-  hipLaunchKernelGGL(k_solve_prepare, dim3((2 * s.nblk + 2) * s.nblk), dim3(256), 0, st, s);
-#endif
   hipLaunchKernelGGL(k_solve_softmax, dim3(KHP), dim3(256), 0, st, lbs, s, Kh);
+#else
+  hipLaunchKernelGGL(k_solve_softmax, dim3(KHP + (2 * s.nblk + 2) * s.nblk), dim3(256), 0, st, lbs, s, Kh);
+#endif
   hipLaunchKernelGGL(k_solve_gram_rows, dim3(s.n_pad), dim3(256), 0, st, L, s, Kh);
 #if ACFM_CHOL_STEPS
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, s);
