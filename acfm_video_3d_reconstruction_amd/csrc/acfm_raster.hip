@@ -1657,8 +1657,13 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
   }
 }
 
+// waves per SIMD the K = 1 kernels are compiled for: 4, 5 and 6 measured the same 70 us on the texture forward (it is
+// VALU-issue bound, 78 % busy, not latency bound), 7 and 8 spill (75 and 90 us)
+#ifndef ACFM_K1_WAVES
+#define ACFM_K1_WAVES 6
+#endif
 template <int K, bool CLIP, bool TEX>
-__global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? 6 : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
+__global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? ACFM_K1_WAVES : 4) void k_raster_fwd(RasterWs ws, int N, int F, int H, float blur,
                                                     float sigma, FwdOut out) {
   __shared__ __attribute__((aligned(16))) FwdLdsK<K> S;
   const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
