@@ -1347,6 +1347,70 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
   }
 }
 
+// The same for images whose side is a multiple of 8 (every block whole), which is where the fills matter: 80 % of
+// the blocks of a batch are empty and the generic routine above spends ~130 VALU instructions per block, a third of
+// them 64-bit multiplies, on addresses that differ from block to block only by a wave-uniform base.  Here every
+// lane's byte offsets inside a block are computed once per workgroup (FillLane) and a block costs one scalar base
+// per output plus the stores (global_store with an SGPR base and a VGPR offset).
+template <int K>
+struct FillLane {
+  unsigned pix;                        // (lane / 8) * H + lane % 8: the lane's pixel inside the block
+  unsigned piece[K > 1 ? K / 2 : 1];   // K > 1: byte offset of the lane's i-th 16-byte piece of the K-slot id rows
+};
+template <int K>
+__device__ __forceinline__ FillLane<K> make_fill_lane(int H, int lane) {
+  FillLane<K> f;
+  f.pix = (unsigned)((lane >> 3) * H + (lane & 7));
+  if constexpr (K > 1) {
+    constexpr int CH = K / 2;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = i * 64 + lane;             // piece index: 8 rows x (8 pixels x CH pieces)
+      const int r = c / (8 * CH), off = c % (8 * CH);
+      f.piece[i] = (unsigned)(r * H * K * 8 + off * 16);
+    }
+  } else {
+    f.piece[0] = 0;
+  }
+  return f;
+}
+template <int K, bool TEX>
+__device__ __forceinline__ void fwd_fill_block_whole(const FwdOut& out, int n, int by, int bx, int H, int lane,
+                                                     const FillLane<K>& fl) {
+  // wave-uniform: first pixel of the block, and the tiles index of its partial-sum record
+  const size_t pix0 = ((size_t)n * H + by) * H + bx;
+  const size_t pix = pix0 + fl.pix;
+  if constexpr (K == 1) {
+    if (TEX && out.lpart && lane == 0) {
+      const int tiles = H / RBLK;
+      out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    st_face(out.p2f, pix, -1, out.h16);
+    if (TEX) {
+      const size_t HW = (size_t)H * H;
+      const size_t io = pix + (size_t)n * 2 * HW;   // [N,3,H,W]: n 3 HW + y W + x
+      st_real(out.imgs, io, 0.f, out.h16); st_real(out.imgs, io + HW, 0.f, out.h16); st_real(out.imgs, io + 2 * HW, 0.f, out.h16);
+      st_real(out.sil, pix, 0.f, out.h16);
+      out.tidx[pix] = -1;
+    }
+  } else {
+    st_real(out.mask, pix, 0.0f, out.h16);
+    if (out.kth) out.kth[pix] = KEY_NONE;
+    if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
+    if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
+      const int tiles = H / RBLK;
+      out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (out.kout == 1) return;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    constexpr int CH = K / 2;
+    ll2 v; v.x = -1; v.y = -1;
+    char* base = reinterpret_cast<char*>(reinterpret_cast<int64_t*>(out.p2f) + pix0 * K);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) P2F_STORE(reinterpret_cast<ll2*>(base + fl.piece[i]), v);
+  }
+}
+
 template <int K, bool CLIP, bool TEX>
 __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
                                           const FwdOut& out, FwdLdsK<K>& S) {
@@ -1691,11 +1755,21 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? ACFM_K1_WAVES : 4) void k
 #else
     constexpr bool no_fill = false;
 #endif
+    if ((H & (RBLK - 1)) == 0) {
+      const FillLane<K> fl = make_fill_lane<K>(H, lane);
 #pragma unroll 1
-    for (int e = e0; e < e1 && !no_fill; ++e) {
-      int n, by, bx;
-      entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
-      fwd_fill_block<K, TEX>(out, n, by, bx, H, lane);
+      for (int e = e0; e < e1 && !no_fill; ++e) {
+        int n, by, bx;
+        entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+        fwd_fill_block_whole<K, TEX>(out, n, by, bx, H, lane, fl);
+      }
+    } else {
+#pragma unroll 1
+      for (int e = e0; e < e1 && !no_fill; ++e) {
+        int n, by, bx;
+        entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+        fwd_fill_block<K, TEX>(out, n, by, bx, H, lane);
+      }
     }
   }
 #pragma unroll 1
