@@ -326,6 +326,11 @@ def main():
     # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
     # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
     dt_fused = timed(renderer, max(2, a.warmup // 2), a.steps, fused=True) if side is None and extras else None
+    # same step with the bit-reproducible silhouette backward (fixed-point accumulation, AcfmRasterTuning flag 1)
+    dt_det = None
+    if side is None and extras:
+        with _lib.raster_tuning(deterministic=True):
+            dt_det = timed(renderer, max(2, a.warmup // 2), a.steps)
 
     # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
     # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
@@ -563,6 +568,12 @@ def main():
                         "pix_to_face [N,H,W,20] still materialised"}
         if lbs_info:
             out["learn_lbs_step"] = lbs_info
+        if dt_det:
+            out["deterministic_backward"] = {
+                "value": round(world * N * a.steps / dt_det, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * dt_det / a.steps, 4),
+                "note": "same step with _lib.raster_tuning(deterministic=True): the silhouette backward accumulates in "
+                        "2^-36 fixed point (int64 atomics), gradients bit-identical from run to run"}
         if dt_lean:
             out["nearest_plane_only"] = {
                 "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",
