@@ -11,6 +11,7 @@ keypoint losses, the hypothesis softmax weighting and the shape priors.  The lea
 
 Tensors follow the reference's shapes: B clips of T frames, N = B*T, G hypotheses, G*N meshes."""
 import math
+import contextlib
 from types import SimpleNamespace
 
 import torch
@@ -47,11 +48,13 @@ def _y_rotation_quats(num_guesses):
 
 
 class MultiframeStep(nn.Module):
-    def __init__(self, mean_v, faces, lbs_logits, num_training_frames, img_size=256, vert2kp=None, **opts):
+    def __init__(self, mean_v, faces, lbs_logits, num_training_frames, img_size=256, vert2kp=None, prior_stream=False,
+                 **opts):
         super().__init__()
         o = dict(DEFAULTS)
         o.update(opts)
         self.opts = SimpleNamespace(**o)
+        self.prior_stream, self._prior_s = bool(prior_stream), None   # mesh priors beside the raster kernels (forward)
         G = self.opts.num_guesses
         self.num_cameras = G          # embeddings; opts.num_guesses may later drop below it (train_utils.py:236-241)
         q0 = _y_rotation_quats(G)
@@ -200,6 +203,25 @@ class MultiframeStep(nn.Module):
         pred_v = pred_v1.repeat(G, 1, 1)
         faces = self.faces1[None].expand(G * N, -1, -1)
         terms = {}
+        # priors on the deformed shape (main.py:698-714, 748-751).  They need the deformed vertices only and are a
+        # dozen one-workgroup-per-mesh kernels (latency bound); prior_stream=True issues them on a second stream
+        # beside the raster kernels (a fork/join when captured into a hipGraph), the streams meet again before the
+        # total is formed.  Off by default: measured on the 96-mesh step it LOSES (2.48 -> 2.73 ms as one hipGraph),
+        # while the simpler 64-frame step of bench.py (survey_8d_step) gains 3.5 % from the same fork.
+        faces_n = self.faces1[None].expand(N * G, -1, -1)
+        cur_s = side_s = None
+        if self.prior_stream and pred_v.is_cuda:
+            cur_s = torch.cuda.current_stream(pred_v.device)
+            if self._prior_s is None or self._prior_s.device != pred_v.device:
+                self._prior_s = torch.cuda.Stream(device=pred_v.device)
+            side_s = self._prior_s
+            side_s.wait_stream(cur_s)
+            pred_v.record_stream(side_s)
+        with (torch.cuda.stream(side_s) if side_s is not None else contextlib.nullcontext()):
+            mesh_3d = Meshes(verts=pred_v, faces=faces_n)
+            mesh_t = Meshes(verts=self.solver.mean_v[None].repeat(G * N, 1, 1), faces=faces_n)
+            triangle = mesh_laplacian_smoothing(mesh_3d, method="cot")
+            rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
         mask_pred, mask_loss, sil_cons = self._silhouette_terms(pred_v, faces, cam, batch, G)
         total = o.mask_loss_wt * mask_loss.reshape(G, N)
         of_term = self._flow_term(pred_v, cam, batch, G)
@@ -236,12 +258,10 @@ class MultiframeStep(nn.Module):
                 pw = self.prob_embeddings.weight
                 cur = torch.zeros_like(pw[fi]).permute(2, 0, 1)                # [G_all,B,T]
                 pw[fi] = torch.scatter(cur, 0, selected, probs.reshape(G, *fi.shape)).permute(1, 2, 0)
-        # priors on the deformed shape (main.py:698-714, 748-751)
-        faces_n = self.faces1[None].expand(N * G, -1, -1)
-        mesh_3d = Meshes(verts=pred_v, faces=faces_n)
-        mesh_t = Meshes(verts=self.solver.mean_v[None].repeat(G * N, 1, 1), faces=faces_n)
-        triangle = mesh_laplacian_smoothing(mesh_3d, method="cot")
-        rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
+        if side_s is not None:
+            cur_s.wait_stream(side_s)
+            triangle.record_stream(cur_s)
+            rigid.record_stream(cur_s)
         handle = loss_utils.deform_l2reg(delta_v_res)
         loss = weighted + o.rigid_wt * rigid + o.triangle_reg_wt * triangle + o.handle_deform_reg_wt * handle
         if textures is not None and imgs is not None:

@@ -20,7 +20,8 @@ m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz")); v, f = m[a.mes
 rng = np.random.default_rng(0); B, T, G, H, Kh = a.B, 2, a.G, a.img, 15
 N = B * T
 step = MultiframeStep(torch.tensor(v, device=d), torch.tensor(f, device=d), torch.tensor(fps_lbs_logits(v, Kh), device=d),
-                      num_training_frames=4 * N, img_size=H, num_guesses=G, num_lbs=Kh, scale_lr_decay=1.0).to(d)
+                      num_training_frames=4 * N, img_size=H, num_guesses=G, num_lbs=Kh, scale_lr_decay=1.0,
+                      prior_stream=os.environ.get("ACFM_PRIOR_STREAM", "0") != "0").to(d)
 gt_cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
 with torch.no_grad():
     gt, _ = step.renderer(step.solver.mean_v[None].repeat(N, 1, 1), step.faces1[None].expand(N, -1, -1), gt_cams)
