@@ -62,6 +62,8 @@ SIGNATURES = {
                                          _vp]),
     "acfm_combine_losses": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "acfm_combine_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "acfm_hypothesis_total": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "acfm_hypothesis_total_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -386,6 +386,84 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombArgs a, int N, const fl
       for (int c = 0; c < a.cols[t]; ++c) a.g[t][(size_t)n * a.cols[t] + c] = a.w[t][c] * g;
 }
 
+// ---- total per hypothesis, softmax weighting over the hypotheses, weighted mean: one launch each way ---------
+// multiframe/main.py:716-746.  One thread per frame n walks its G hypotheses; everything is summed in a fixed
+// order (one workgroup), so the result is reproducible.
+constexpr int HYP_MAX_TERMS = 8;
+struct HypArgs {
+  const float* t[HYP_MAX_TERMS];
+  float* g[HYP_MAX_TERMS];
+  float w[HYP_MAX_TERMS];
+  float aux_w[HYP_MAX_TERMS];
+  int aux_group[HYP_MAX_TERMS];   // -1, 0 or 1: which auxiliary sum the term also enters (with aux_w)
+  int nterms;
+};
+__global__ __launch_bounds__(256) void k_hyp_total(HypArgs a, int G, int N, float* __restrict__ total,
+                                                   float* __restrict__ probs, float* __restrict__ aux0,
+                                                   float* __restrict__ aux1, float* __restrict__ out) {
+  __shared__ float s_red[4][4 + HYP_MAX_TERMS];
+  float acc_w = 0.f, acc_t = 0.f, acc_a0 = 0.f, acc_a1 = 0.f, acc_term[HYP_MAX_TERMS];
+#pragma unroll
+  for (int t = 0; t < HYP_MAX_TERMS; ++t) acc_term[t] = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float lmin = __builtin_inff();
+    for (int g = 0; g < G; ++g) {
+      const size_t i = (size_t)g * N + n;
+      float tot = 0.f, x0 = 0.f, x1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HYP_MAX_TERMS; ++t) {
+        if (t >= a.nterms) break;
+        const float v = a.t[t][i];
+        tot += a.w[t] * v;
+        acc_term[t] += v;
+        if (a.aux_group[t] == 0) x0 += a.aux_w[t] * v;
+        if (a.aux_group[t] == 1) x1 += a.aux_w[t] * v;
+      }
+      total[i] = tot;
+      if (aux0) aux0[i] = x0;
+      if (aux1) aux1[i] = x1;
+      acc_t += tot; acc_a0 += x0; acc_a1 += x1;
+      lmin = fminf(lmin, tot);
+    }
+    float den = 0.f;
+    for (int g = 0; g < G; ++g) den += expf(-(total[(size_t)g * N + n] - lmin));   // softmax(-total) over g
+    float wsum = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const size_t i = (size_t)g * N + n;
+      const float p = expf(-(total[i] - lmin)) / den;
+      probs[i] = p;
+      wsum += p * total[i];
+    }
+    acc_w += wsum;
+  }
+  // out: [0] weighted loss, [1] mean total, [2] mean aux0, [3] mean aux1, [4 + t] mean of term t
+  float vals[4 + HYP_MAX_TERMS] = {acc_w, acc_t, acc_a0, acc_a1};
+#pragma unroll
+  for (int t = 0; t < HYP_MAX_TERMS; ++t) vals[4 + t] = acc_term[t];
+#pragma unroll
+  for (int k = 0; k < 4 + HYP_MAX_TERMS; ++k) {
+    const float v = wave_sum(vals[k]);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 + HYP_MAX_TERMS) {
+    const int k = threadIdx.x;
+    const float v = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+    out[k] = v / (k == 0 ? (float)N : (float)N * (float)G);
+  }
+}
+__global__ __launch_bounds__(256) void k_hyp_total_bwd(HypArgs a, int GN, int N, const float* __restrict__ go,
+                                                       const float* __restrict__ probs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= GN) return;
+  const float g = go[0] * probs[i] / (float)N;   // the probabilities carry no gradient (detached in the reference)
+#pragma unroll
+  for (int t = 0; t < HYP_MAX_TERMS; ++t) {
+    if (t >= a.nterms) break;
+    if (a.g[t]) a.g[t][i] = a.w[t] * g;
+  }
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -477,6 +555,49 @@ int acfm_combine_losses_backward(const float* grad_total, void* const* grads, co
   if (!grad_total || !grads || N <= 0 || fill_comb(a, nullptr, grads, cols, weights, nterms) != ACFM_OK)
     return ACFM_E_BADARG;
   hipLaunchKernelGGL(k_combine_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, N, grad_total);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_hypothesis_total(const void* const* terms, const float* weights, const int* aux_group, const float* aux_weights,
+                          int nterms, int G, int N, float* total, float* probs, float* aux0, float* aux1, float* out,
+                          void* stream) {
+  if (!terms || !weights || !total || !probs || !out || nterms < 1 || nterms > HYP_MAX_TERMS || G <= 0 || G > 4096 ||
+      N <= 0 || (size_t)G * N > 0x7fffffffull)
+    return ACFM_E_BADARG;
+  HypArgs a;
+  for (int t = 0; t < HYP_MAX_TERMS; ++t) {
+    a.t[t] = t < nterms ? (const float*)terms[t] : nullptr;
+    a.g[t] = nullptr;
+    a.w[t] = t < nterms ? weights[t] : 0.f;
+    a.aux_group[t] = (t < nterms && aux_group) ? aux_group[t] : -1;
+    a.aux_w[t] = (t < nterms && aux_weights) ? aux_weights[t] : 0.f;
+    if (t < nterms && !a.t[t]) return ACFM_E_BADARG;
+    if (a.aux_group[t] < -1 || a.aux_group[t] > 1) return ACFM_E_BADARG;
+  }
+  a.nterms = nterms;
+  hipLaunchKernelGGL(k_hyp_total, dim3(1), dim3(256), 0, (hipStream_t)stream, a, G, N, total, probs, aux0, aux1, out);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_hypothesis_total_backward(const float* grad_weighted, const float* probs, const float* weights, int nterms,
+                                   int G, int N, void* const* grads, void* stream) {
+  if (!grad_weighted || !probs || !weights || !grads || nterms < 1 || nterms > HYP_MAX_TERMS || G <= 0 || N <= 0 ||
+      (size_t)G * N > 0x7fffffffull)
+    return ACFM_E_BADARG;
+  HypArgs a;
+  for (int t = 0; t < HYP_MAX_TERMS; ++t) {
+    a.t[t] = nullptr;
+    a.g[t] = t < nterms ? (float*)grads[t] : nullptr;
+    a.w[t] = t < nterms ? weights[t] : 0.f;
+    a.aux_group[t] = -1;
+    a.aux_w[t] = 0.f;
+  }
+  a.nterms = nterms;
+  const int GN = G * N;
+  hipLaunchKernelGGL(k_hyp_total_bwd, dim3((GN + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, GN, N,
+                     grad_weighted, probs);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

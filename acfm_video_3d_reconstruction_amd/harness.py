@@ -60,6 +60,25 @@ def transform_cameras(sfm_pose, im_shape, transforms):
     return (1 - flag) * sfm_pose + new * flag
 
 
+def hypothesis_total(terms, weights, G, N, aux_group=None, aux_weights=None):
+    """multiframe/main.py:716-746 in one launch each way on the GPU (ops.hypothesis_total); on the CPU the same from
+    torch ops.  Returns (weighted, total [G,N], probs [G,N], aux [2,G,N], means [12])."""
+    ts = [t.reshape(G, N) for t in terms]
+    if ts[0].is_cuda:
+        from . import ops
+        return ops.hypothesis_total(ts, weights, G, N, aux_group, aux_weights)
+    total = sum(float(w) * t for w, t in zip(weights, ts))
+    weighted, probs, mean_total = hypothesis_weighting(total)
+    aux = torch.zeros(2, G, N, dtype=total.dtype)
+    if aux_group is not None:
+        for t, k, w in zip(ts, aux_group, aux_weights):
+            if k >= 0:
+                aux[k] = aux[k] + float(w) * t.detach()
+    means = torch.stack([weighted.detach(), mean_total.detach(), aux[0].mean(), aux[1].mean()]
+                        + [t.detach().mean() for t in ts] + [total.new_zeros(())] * (8 - len(ts)))
+    return weighted, total.detach(), probs, aux, means
+
+
 def hypothesis_weighting(loss_per_hyp):
     """multiframe/main.py:735-745: loss [G, B*T] -> (total = mean_n sum_g w*L,
     w = softmax(-L, 0) detached, mean loss that the reference logs as `camera_loss`)."""

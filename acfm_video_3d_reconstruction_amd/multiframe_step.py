@@ -118,7 +118,7 @@ class MultiframeStep(nn.Module):
             cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
         return cam_pred.detach() if detach else cam_pred
 
-    def _silhouette_terms(self, pred_v, faces, cam, batch, G):
+    def _silhouette_terms(self, pred_v, faces, cam, batch, G, parts=False):
         o = self.opts
         mask_pred, pix_to_face = self.renderer(pred_v, faces, cam)
         # the frame's ground truth is shared by its G hypotheses (the loss kernels index it n % N: the
@@ -126,6 +126,8 @@ class MultiframeStep(nn.Module):
         l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, batch["masks"], batch["edts_barrier"])
         pred_proj = self.renderer.project_points(pred_v, cam)
         bdt = loss_utils.bds_loss(pred_proj, batch["boundaries"], faces, pix_to_face, reduce=False)
+        if parts:
+            return mask_pred, l1, edt, bdt
         sil_cons = o.edt_reg_wt * edt + o.bdt_reg_wt * bdt
         return mask_pred, l1, sil_cons
 
@@ -222,19 +224,23 @@ class MultiframeStep(nn.Module):
             mesh_t = Meshes(verts=self.solver.mean_v[None].repeat(G * N, 1, 1), faces=faces_n)
             triangle = mesh_laplacian_smoothing(mesh_3d, method="cot")
             rigid = loss_utils.locally_rigid_fn(mesh_3d, mesh_t)
-        mask_pred, mask_loss, sil_cons = self._silhouette_terms(pred_v, faces, cam, batch, G)
-        total = o.mask_loss_wt * mask_loss.reshape(G, N)
+        # The per-hypothesis total (main.py:716-734: weight * term + ...) and its weighting over the hypotheses
+        # (:735-746) are formed from the terms by ONE operator each way (harness.hypothesis_total), which also
+        # returns the sums the reference logs; the terms themselves come from the kernels above.
+        mask_pred, mask_loss, edt, bdt = self._silhouette_terms(pred_v, faces, cam, batch, G, parts=True)
         of_term = self._flow_term(pred_v, cam, batch, G)
-        total = total + o.of_loss_wt * of_term
-        total = total + o.boundaries_reg_wt * sil_cons.reshape(G, N)
-        terms.update(cam_pred=cam.detach(), pred_v=pred_v1.detach(), mask_loss=mask_loss.reshape(G, N).detach(),
-                     sil_cons_per_hyp=sil_cons.reshape(G, N).detach(), of_loss=of_term.detach())
+        tl, tw, tg, ta = [mask_loss, edt, bdt], [o.mask_loss_wt, o.boundaries_reg_wt * o.edt_reg_wt,
+                                                  o.boundaries_reg_wt * o.bdt_reg_wt], [-1, 0, 0], \
+            [0.0, o.edt_reg_wt, o.bdt_reg_wt]
+        if of_term.numel() == G * N:
+            tl.append(of_term); tw.append(o.of_loss_wt); tg.append(-1); ta.append(0.0)
         if o.kp_loss_wt > 0 and self.vert2kp is not None:
             kp_v = torch.matmul(torch.softmax(self.vert2kp, dim=1), pred_v)
             kp = loss_utils.kp_l2_loss(self.renderer.project_points(kp_v, cam), batch["kps"].repeat(G, 1, 1),
                                        reduction="none")
-            total = total + o.kp_loss_wt * kp.reshape(G, N)
-        if textures is not None and imgs is not None:
+            tl.append(kp); tw.append(o.kp_loss_wt); tg.append(-1); ta.append(0.0)
+        have_tex = textures is not None and imgs is not None
+        if have_tex:
             # texture branch on detached geometry, original + mirrored camera (main.py:627-636, 655-662;
             # the LPIPS part of the reference's texture loss is out of scope)
             tex = textures    # [N,...] shared by the G hypotheses of a frame: the op indexes n % N (= repeat(G))
@@ -243,15 +249,17 @@ class MultiframeStep(nn.Module):
             imgs_f, masks_f = torch.flip(imgs, dims=(3,)), torch.flip(batch["masks"], dims=(2,))
             cam_f = harness._mirrored_pose(cam)
             tex_pred_f, _, _ = self.tex_renderer(pred_v.detach(), faces, cam_f, textures=tex)
-            mse = 0.5 * (loss_utils.masked_texture_mse(tex_pred, imgs, batch["masks"])
-                         + loss_utils.masked_texture_mse(tex_pred_f, imgs_f, masks_f))
-            total = total + o.tex_loss_wt * mse.reshape(G, N)
-            terms["tex_mse"] = mse.mean().detach()
-            terms["tex_mse_per_hyp"] = mse.reshape(G, N).detach()
+            tl += [loss_utils.masked_texture_mse(tex_pred, imgs, batch["masks"]),
+                   loss_utils.masked_texture_mse(tex_pred_f, imgs_f, masks_f)]          # mse = their mean
+            tw += [0.5 * o.tex_loss_wt] * 2; tg += [1, 1]; ta += [0.5, 0.5]
             cycle = texture_cycle_loss(textures, T)              # main.py:705-711, added at :749
-        # hypothesis weighting (main.py:735-746)
-        weighted, probs, cam_loss = harness.hypothesis_weighting(total)
-        terms.update(total_per_hyp=total.detach(), weighted=weighted.detach())
+        weighted, total, probs, aux, means = harness.hypothesis_total(tl, tw, G, N, tg, ta)
+        cam_loss = means[1]
+        terms.update(cam_pred=cam.detach(), pred_v=pred_v1.detach(), mask_loss=mask_loss.reshape(G, N).detach(),
+                     sil_cons_per_hyp=aux[0], of_loss=of_term.detach(), total_per_hyp=total, weighted=weighted.detach())
+        if have_tex:
+            terms["tex_mse"] = means[3]
+            terms["tex_mse_per_hyp"] = aux[1]
         if selected is not None:                   # probabilities go back to the embeddings they came from (:737-742)
             with torch.no_grad():
                 fi = batch["frames_idx"]
@@ -277,6 +285,6 @@ class MultiframeStep(nn.Module):
             deform_loss = torch.nn.functional.mse_loss(delta_v_res, deforms.detach())
             loss = loss + o.deform_loss_wt * deform_loss
             terms["deform_loss"] = deform_loss.detach()
-        terms.update(mask=mask_loss.mean().detach(), sil_cons=sil_cons.mean().detach(), rigid=rigid.detach(),
+        terms.update(mask=means[4], sil_cons=means[2], rigid=rigid.detach(),
                      triangle=triangle.detach(), camera_loss=cam_loss.detach(), probs=probs)
         return loss, terms

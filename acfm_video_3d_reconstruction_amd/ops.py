@@ -898,6 +898,60 @@ def combine_losses(terms, weights):
     return _Combine.apply(tuple(float(w) for w in weights), *terms)
 
 
+class _HypTotal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, aux_group, aux_weights, G, N, *terms):
+        _lib.require_gpu(*terms)
+        ts = [_f32c(t).reshape(-1) for t in terms]
+        nt = len(ts)
+        if not 1 <= nt <= 8 or any(t.numel() != G * N for t in ts) or len(weights) != nt:
+            raise ValueError("hypothesis_total: 1..8 terms of G*N elements, one weight each")
+        dev = ts[0].device
+        total = torch.empty((G, N), dtype=torch.float32, device=dev)
+        probs = torch.empty((G, N), dtype=torch.float32, device=dev)
+        aux = torch.empty((2, G, N), dtype=torch.float32, device=dev)
+        out = torch.empty(12, dtype=torch.float32, device=dev)
+        w = (ctypes.c_float * nt)(*[float(x) for x in weights])
+        ag = (ctypes.c_int * nt)(*[int(x) for x in aux_group])
+        aw = (ctypes.c_float * nt)(*[float(x) for x in aux_weights])
+        ptrs = (ctypes.c_void_p * nt)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().acfm_hypothesis_total(ptrs, w, ag, aw, nt, G, N, _lib.ptr(total), _lib.ptr(probs),
+                                                        _lib.ptr(aux[0]), _lib.ptr(aux[1]), _lib.ptr(out),
+                                                        _lib.cur_stream(dev)), "acfm_hypothesis_total")
+        ctx.args = (w, nt, G, N, [t.shape for t in terms])
+        ctx.save_for_backward(probs)
+        ctx.mark_non_differentiable(total, probs, aux, out)
+        return out[0], total, probs, aux, out
+
+    @staticmethod
+    def backward(ctx, go, *_):
+        w, nt, G, N, shapes = ctx.args
+        probs, = ctx.saved_tensors
+        g = _f32c(go).reshape(1)
+        need = ctx.needs_input_grad[5:]
+        outs = [torch.empty((G, N), dtype=torch.float32, device=g.device) if need[i] else None for i in range(nt)]
+        ptrs = (ctypes.c_void_p * nt)(*[(o.data_ptr() if o is not None else None) for o in outs])
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_hypothesis_total_backward(_lib.ptr(g), _lib.ptr(probs), w, nt, G, N, ptrs,
+                                                                 _lib.cur_stream(g.device)),
+                       "acfm_hypothesis_total_backward")
+        return (None,) * 5 + tuple(o.reshape(shapes[i]) if o is not None else None for i, o in enumerate(outs))
+
+
+def hypothesis_total(terms, weights, G, N, aux_group=None, aux_weights=None):
+    """Per-hypothesis total, its softmax weighting and the weighted mean (multiframe/main.py:716-746) as one launch
+    each way.  terms: 1..8 tensors of G*N elements (row g*N + n); weights: one float each.
+    Returns (weighted, total [G,N], probs [G,N], aux [2,G,N], means [12]): weighted = (1/N) sum_n sum_g probs total with
+    probs = softmax(-total, dim 0) carrying no gradient; aux[k] = sum of aux_weights[t] * terms[t] over the terms with
+    aux_group[t] == k; means = (weighted, mean total, mean aux0, mean aux1, mean of each term ...).  Only `weighted`
+    is differentiable."""
+    nt = len(terms)
+    ag = tuple(aux_group) if aux_group is not None else (-1,) * nt
+    aw = tuple(aux_weights) if aux_weights is not None else (0.0,) * nt
+    return _HypTotal.apply(tuple(float(w) for w in weights), ag, aw, int(G), int(N), *terms)
+
+
 # ------------------------------------------------------------------------------ boundary loss
 def visible_vertices(pix_to_face, faces, nv):
     """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv].  A pix_to_face tensor that

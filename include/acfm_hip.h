@@ -333,6 +333,22 @@ int acfm_combine_losses(const void* const* terms, const int* cols, const float* 
 int acfm_combine_losses_backward(const float* grad_total, void* const* grads, const int* cols,
                                  const float* weights, int nterms, int N, void* stream);
 
+/* ---- total per hypothesis + hypothesis weighting --------------------------------------------------
+ * replaces the per-hypothesis total of ShapeTrainer.forward and its softmax weighting (multiframe/main.py:716-746:
+ * weight * term + ..., probs = softmax(-total, dim 0).detach(), (total * probs).sum(0).mean()) by one launch each way:
+ *   total[g,n] = sum_t w_t T_t[g,n]  for nterms <= 8 terms T_t [G*N] f32 (row g*N + n);
+ *   probs[g,n] = softmax over g of -total[.,n];   out[0] = (1/N) sum_n sum_g probs total (the weighted loss),
+ *   out[1] = mean total (what the reference logs as camera_loss), out[2..3] = means of the two auxiliary sums
+ *   aux_k[g,n] = sum_{t: aux_group[t] == k} aux_weights[t] T_t[g,n] (logged terms such as sil_cons; aux0 / aux1 and
+ *   aux_group / aux_weights may be NULL), out[4 + t] = mean of term t.  out: 12 floats.
+ * backward: grads[t][g,n] = grad_weighted * w_t * probs[g,n] / N (NULL grads[t] skipped); probs carry no gradient.
+ * terms / grads / weights / aux_* are HOST arrays (device pointers inside terms and grads). */
+int acfm_hypothesis_total(const void* const* terms, const float* weights, const int* aux_group, const float* aux_weights,
+                          int nterms, int G, int N, float* total, float* probs, float* aux0, float* aux1, float* out,
+                          void* stream);
+int acfm_hypothesis_total_backward(const float* grad_weighted, const float* probs, const float* weights, int nterms,
+                                   int G, int N, void* const* grads, void* stream);
+
 /* ---- fused silhouette losses ---------------------------------------------------------
  * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False
  * (multiframe/nnutils/loss_utils.py:18-32, 72-77, 245-253) in one pass over the mask:

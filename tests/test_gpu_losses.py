@@ -600,6 +600,45 @@ def test_losses_with_references_shared_by_hypotheses(meshes):
 
 
 @pytest.mark.gpu
+def test_hypothesis_total_matches_the_torch_formula():
+    """harness.hypothesis_total == the reference's per-hypothesis total + softmax weighting (multiframe/main.py:716-746:
+    total = sum w_t T_t, probs = softmax(-total, 0).detach(), weighted = (total * probs).sum(0).mean()), the logged sums
+    and the gradients; one launch each way on the GPU, the same torch formula on the CPU path."""
+    from acfm_video_3d_reconstruction_amd import harness
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for G, N in ((1, 1), (6, 16), (8, 300), (3, 2000)):
+        raw = [torch.rand(G * N, generator=g) * s for s in (1.0, 0.1, 3.0, 0.5, 2.0)]
+        w = [1.0, 0.25, 2.0, 0.0, 0.5]
+        ag, aw = [-1, 0, 0, 1, 1], [0.0, 0.1, 2.0, 0.5, 0.5]
+        ts = [t.to(d).requires_grad_(i != 3) for i, t in enumerate(raw)]
+        weighted, total, probs, aux, means = harness.hypothesis_total(ts, w, G, N, ag, aw)
+        rs = [t.double().reshape(G, N).requires_grad_(True) for t in raw]
+        rt = sum(wi * t for wi, t in zip(w, rs))
+        rp = torch.softmax(-rt, dim=0).detach()
+        rw = (rt * rp).sum(0).mean()
+        np.testing.assert_allclose(total.cpu().numpy(), rt.detach().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(probs.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(probs.sum(0).cpu().numpy(), 1.0, atol=1e-6)
+        np.testing.assert_allclose(weighted.item(), rw.item(), rtol=1e-6)
+        np.testing.assert_allclose(aux[0].cpu().numpy(), (0.1 * rs[1] + 2.0 * rs[2]).detach().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(aux[1].cpu().numpy(), (0.5 * rs[3] + 0.5 * rs[4]).detach().numpy(), rtol=1e-6, atol=1e-7)
+        want = [rw.item(), rt.mean().item(), (0.1 * rs[1] + 2.0 * rs[2]).mean().item(),
+                (0.5 * rs[3] + 0.5 * rs[4]).mean().item()] + [t.mean().item() for t in rs]
+        np.testing.assert_allclose(means.cpu().numpy()[:9], want, rtol=2e-6)
+        gs = torch.autograd.grad(weighted * 2.0, [ts[0], ts[1], ts[2], ts[4]])
+        rg = torch.autograd.grad(rw * 2.0, [rs[0], rs[1], rs[2], rs[4]])
+        for a, b in zip(gs, rg):
+            np.testing.assert_allclose(a.cpu().numpy().reshape(G, N), b.numpy(), rtol=1e-5, atol=1e-9)
+        # the CPU path of the same wrapper (torch ops) agrees
+        cw, ct, cp, ca, cm = harness.hypothesis_total([t.reshape(G, N) for t in raw], w, G, N, ag, aw)
+        np.testing.assert_allclose(cw.item(), rw.item(), rtol=1e-5)
+        np.testing.assert_allclose(cm.numpy()[:9], want, rtol=1e-5)
+    with pytest.raises(ValueError):
+        harness.hypothesis_total([ts[0]], [1.0, 2.0], G, N)
+
+
+@pytest.mark.gpu
 def test_combine_losses_matches_the_torch_formula():
     """combine_losses([T0 [N,4], T1 [N], T2 [N]], w) == mean_n(sum of weighted columns), gradients
     included (multiframe/main.py:716-765's elementwise tail as one launch each way)."""
