@@ -6,10 +6,11 @@
 // (multiframe/main.py:586-609).  Both the mean shape and lbs are learned, so M changes every
 // optimiser step: one V x V SPD factorisation per step is part of the training hot path.  This
 // file does it once per step for all frames (deform.py) as a blocked Cholesky with 32 x 32 tiles,
-// fp64 throughout (v_mfma_f64_16x16x4_f64), in four launches:
+// fp64 throughout (v_mfma_f64_16x16x4_f64), in three launches:
 //
-//   k_solve_prepare   sentinel fill of the tiles the factorisation publishes, status / ticket reset
-//   k_solve_softmax   A = softmax over vertices of each handle's logits (fp64), one WG per handle
+//   k_solve_softmax   A = softmax over vertices of each handle's logits (fp64), one WG per handle; the workgroups
+//                     beyond the 32 handles fill the sentinels of the tiles the factorisation publishes
+//                     (solve_prepare_block) and reset the status word and the job ticket
 //   k_solve_gram_rows W = L^T L + A^T A, one WG per row; only the non-zeros of L's column are
 //                     visited (the cotangent Laplacian has ~7 per column), fixed summation order
 //   k_chol_tiles      ONE launch for the factorisation and both substitutions: every tile of the
