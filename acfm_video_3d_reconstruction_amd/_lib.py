@@ -33,6 +33,8 @@ SIGNATURES = {
     "acfm_of_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_camera_pipeline": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_pipeline_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "acfm_camera_pipeline_tables": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "acfm_camera_pipeline_tables_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_normalize": (_i, [_vp, _i, _vp, _vp]),
     "acfm_camera_normalize_backward": (_i, [_vp, _vp, _i, _vp, _vp]),
     "acfm_deform_solve_workspace_bytes": (_sz, [_i, _i]),

@@ -60,17 +60,10 @@ __global__ void k_camera_fwd(const float* __restrict__ emb, const int64_t* __res
   for (int k = 0; k < 7; ++k) out[(size_t)r * 7 + k] = o[k];
 }
 
-__global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __restrict__ mirror,
-                             const float* __restrict__ transforms, const float* __restrict__ gout, int R,
-                             int N, float decay, float* __restrict__ gemb) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  const int n = r % N;
-  float e[7], o[7], g[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) { e[k] = emb[(size_t)r * 7 + k]; g[k] = gout[(size_t)r * 7 + k]; }
-  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
-  const float m = (float)mirror[n];
+// d embedding from d camera (the forward is re-evaluated)
+__device__ __forceinline__ void cam_backward(const float* __restrict__ e, const float* __restrict__ g, float decay, float m,
+                                             const float* __restrict__ tr, float* __restrict__ ge) {
+  float o[7];
   CamFwd c;
   cam_forward(e, decay, m, tr, o, c);
   const float a = tr[0], f = tr[3];
@@ -93,7 +86,6 @@ __global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __res
   float gq[4] = {gpose[3] + c.b_sign * gr2, gpose[4] - c.b_sign * gr3, gpose[5] - c.b_sign * gr0,
                  gpose[6] + c.b_sign * gr1};
   // q = e / max(|e|, eps)
-  float ge[7];
   if (c.nrm > 1e-12f) {
     const float dot = c.q[0] * gq[0] + c.q[1] * gq[1] + c.q[2] * gq[2] + c.q[3] * gq[3];
 #pragma unroll
@@ -105,8 +97,67 @@ __global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __res
   ge[0] = c.relu_on ? decay * gs : 0.0f;
   ge[1] = ge1;
   ge[2] = ge2;
+}
+
+
+// The same straight from the per-hypothesis embedding tables (mesh_net.py:436-444: one nn.Embedding(frames, 7) per
+// hypothesis): row r = g N + n reads tables[sel ? sel[r] : g][frames_idx[n]]; the backward adds into dense per-table
+// gradients (zeroed by the caller; float atomics: frames of a batch are distinct, so every cell gets one add).
+constexpr int CAM_MAX_TABLES = 32;
+struct CamTables {
+  const float* t[CAM_MAX_TABLES];
+  float* g[CAM_MAX_TABLES];
+};
+__global__ void k_camera_fwd_tables(CamTables tb, const int64_t* __restrict__ frames_idx, const int64_t* __restrict__ sel,
+                                    const int64_t* __restrict__ mirror, const float* __restrict__ transforms, int R, int N,
+                                    float decay, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int n = r % N;
+  const int table = sel ? (int)sel[r] : r / N;
+  const float* src = tb.t[table] + (size_t)frames_idx[n] * 7;
+  float e[7], o[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) e[k] = src[k];
+  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
+  CamFwd c;
+  cam_forward(e, decay, (float)mirror[n], tr, o, c);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) out[(size_t)r * 7 + k] = o[k];
+}
+
+__global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __restrict__ mirror,
+                             const float* __restrict__ transforms, const float* __restrict__ gout, int R,
+                             int N, float decay, float* __restrict__ gemb) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int n = r % N;
+  float e[7], g[7], ge[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { e[k] = emb[(size_t)r * 7 + k]; g[k] = gout[(size_t)r * 7 + k]; }
+  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
+  cam_backward(e, g, decay, (float)mirror[n], tr, ge);
 #pragma unroll
   for (int k = 0; k < 7; ++k) gemb[(size_t)r * 7 + k] = ge[k];
+}
+
+__global__ void k_camera_bwd_tables(CamTables tb, const int64_t* __restrict__ frames_idx, const int64_t* __restrict__ sel,
+                                    const int64_t* __restrict__ mirror, const float* __restrict__ transforms,
+                                    const float* __restrict__ gout, int R, int N, float decay) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int n = r % N;
+  const int table = sel ? (int)sel[r] : r / N;
+  if (!tb.g[table]) return;
+  const size_t row = (size_t)frames_idx[n] * 7;
+  const float* src = tb.t[table] + row;
+  float e[7], g[7], ge[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { e[k] = src[k]; g[k] = gout[(size_t)r * 7 + k]; }
+  const float tr[4] = {transforms[4 * n], transforms[4 * n + 1], transforms[4 * n + 2], transforms[4 * n + 3]};
+  cam_backward(e, g, decay, (float)mirror[n], tr, ge);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) atomicAdd(tb.g[table] + row + k, ge[k]);
 }
 
 // cam = (s, tx, ty, q / max(|q|, 1e-12)): the camera the refinement loop renders with while it
@@ -166,6 +217,45 @@ int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, 
     return ACFM_E_BADARG;
   hipLaunchKernelGGL(k_camera_bwd, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, emb, mirror_flag,
                      transforms, grad_cams, R, N, scale_lr_decay, grad_emb);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_pipeline_tables(const void* const* tables, int n_tables, int n_frames, const int64_t* frames_idx,
+                                const int64_t* selected, const int64_t* mirror_flag, const float* transforms, int R,
+                                int N, float scale_lr_decay, float* cams, void* stream) {
+  if (!tables || !frames_idx || !mirror_flag || !transforms || !cams || n_tables <= 0 || n_tables > CAM_MAX_TABLES ||
+      n_frames <= 0 || R <= 0 || N <= 0 || R % N != 0 || (!selected && R / N > n_tables))
+    return ACFM_E_BADARG;
+  CamTables tb;
+  for (int i = 0; i < CAM_MAX_TABLES; ++i) {
+    tb.t[i] = i < n_tables ? (const float*)tables[i] : nullptr;
+    tb.g[i] = nullptr;
+    if (i < n_tables && !tb.t[i]) return ACFM_E_BADARG;
+  }
+  hipLaunchKernelGGL(k_camera_fwd_tables, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, tb, frames_idx,
+                     selected, mirror_flag, transforms, R, N, scale_lr_decay, cams);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_pipeline_tables_backward(const void* const* tables, int n_tables, int n_frames, const int64_t* frames_idx,
+                                         const int64_t* selected, const int64_t* mirror_flag, const float* transforms,
+                                         const float* grad_cams, int R, int N, float scale_lr_decay,
+                                         void* const* grad_tables, void* stream) {
+  if (!tables || !grad_tables || !frames_idx || !mirror_flag || !transforms || !grad_cams || n_tables <= 0 ||
+      n_tables > CAM_MAX_TABLES || n_frames <= 0 || R <= 0 || N <= 0 || R % N != 0 || (!selected && R / N > n_tables))
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  CamTables tb;
+  for (int i = 0; i < CAM_MAX_TABLES; ++i) {
+    tb.t[i] = i < n_tables ? (const float*)tables[i] : nullptr;
+    tb.g[i] = i < n_tables ? (float*)grad_tables[i] : nullptr;
+    if (i < n_tables && !tb.t[i]) return ACFM_E_BADARG;
+    if (tb.g[i] && zero_async(tb.g[i], sizeof(float) * 7 * (size_t)n_frames, st) != ACFM_OK) return ACFM_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(k_camera_bwd_tables, dim3((R + 127) / 128), dim3(128), 0, st, tb, frames_idx, selected,
+                     mirror_flag, transforms, grad_cams, R, N, scale_lr_decay);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

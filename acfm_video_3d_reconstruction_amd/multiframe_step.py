@@ -105,17 +105,20 @@ class MultiframeStep(nn.Module):
     # ------------------------------------------------------------------ cameras (main.py:551-584)
     def hypothesis_cameras(self, frames_idx, mirror_flag, transforms, detach=False, selected=None):
         G = self.opts.num_guesses
+        w0 = self.cameras[0].weight
+        if w0.is_cuda:   # look-ups + stack / top-k gather + decode + mirror + transform fused (csrc/acfm_camera.hip)
+            from . import ops
+            cam_pred = ops.camera_pipeline_tables([emb.weight for emb in self.cameras], frames_idx, mirror_flag,
+                                                  transforms, self.opts.scale_lr_decay, num_guesses=G,
+                                                  selected=selected)
+            return cam_pred.detach() if detach else cam_pred
         cams = torch.stack([emb(frames_idx) for emb in self.cameras])          # [G_all,B,T,7]
         if selected is not None:                                               # main.py:568-570
             cams = torch.gather(cams, 0, selected[..., None].expand(-1, -1, -1, 7))
-        cams = cams.reshape(G, -1, 7)
-        if cams.is_cuda:       # decode + mirror + transform fused (csrc/acfm_camera.hip)
-            from . import ops
-            cam_pred = ops.camera_pipeline(cams, mirror_flag, transforms, self.opts.scale_lr_decay)
-        else:
-            cam_pred = harness.decode_cameras(cams, self.opts.scale_lr_decay).reshape(-1, 7)
-            cam_pred = harness.mirror_cameras(cam_pred, None, mirror_flag.repeat(G)[:, None])
-            cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
+        cams = cams.reshape(G, -1, 7)          # (host tensors: the reference's chain of torch ops, harness.py)
+        cam_pred = harness.decode_cameras(cams, self.opts.scale_lr_decay).reshape(-1, 7)
+        cam_pred = harness.mirror_cameras(cam_pred, None, mirror_flag.repeat(G)[:, None])
+        cam_pred = harness.transform_cameras(cam_pred, None, transforms.repeat(G, 1))
         return cam_pred.detach() if detach else cam_pred
 
     def _silhouette_terms(self, pred_v, faces, cam, batch, G, parts=False):

@@ -331,6 +331,63 @@ def camera_pipeline(cam_emb, mirror_flag, transforms, scale_lr_decay=1.0):
     return _CameraPipeline.apply(cam_emb, mirror_flag, transforms, scale_lr_decay)
 
 
+class _CameraPipelineTables(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, frames_idx, selected, mirror_flag, transforms, decay, G, *tables):
+        _lib.require_gpu(frames_idx, mirror_flag, transforms, *tables)
+        ts = [_f32c(t) for t in tables]
+        F = ts[0].shape[0]
+        if not 1 <= len(ts) <= 32 or any(t.dim() != 2 or tuple(t.shape) != (F, 7) for t in ts):
+            raise ValueError("camera_pipeline_tables: 1..32 embedding tables [frames, 7] of one size")
+        fi = frames_idx.detach().reshape(-1).to(torch.int64).contiguous()
+        mf = mirror_flag.detach().reshape(-1).to(torch.int64).contiguous()
+        tr = _f32c(transforms).reshape(-1, 4)
+        N = fi.numel()
+        R = int(G) * N
+        sel = None if selected is None else selected.detach().reshape(-1).to(torch.int64).contiguous()
+        if mf.numel() != N or tr.shape[0] != N or (sel is not None and sel.numel() != R) or \
+                (sel is None and int(G) > len(ts)):
+            raise ValueError("camera_pipeline_tables: %d frames, mirror flags %d, transforms %s, G = %d, %d tables"
+                             % (N, mf.numel(), tuple(tr.shape), G, len(ts)))
+        out = torch.empty((R, 7), dtype=torch.float32, device=ts[0].device)
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().acfm_camera_pipeline_tables(
+                ptrs, len(ts), F, _lib.ptr(fi), _lib.ptr(sel) if sel is not None else None, _lib.ptr(mf), _lib.ptr(tr),
+                R, N, float(decay), _lib.ptr(out), _lib.cur_stream(out.device)), "acfm_camera_pipeline_tables")
+        ctx.save_for_backward(fi, mf, tr, *ts) if sel is None else ctx.save_for_backward(fi, mf, tr, sel, *ts)
+        ctx.cfg = (float(decay), R, N, F, len(ts), sel is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        decay, R, N, F, nt, has_sel = ctx.cfg
+        saved = ctx.saved_tensors
+        fi, mf, tr = saved[:3]
+        sel = saved[3] if has_sel else None
+        ts = saved[4:] if has_sel else saved[3:]
+        g = _f32c(g)
+        need = ctx.needs_input_grad[6:]
+        outs = [torch.empty((F, 7), dtype=torch.float32, device=g.device) if need[i] else None for i in range(nt)]
+        ptrs = (ctypes.c_void_p * nt)(*[t.data_ptr() for t in ts])
+        gptrs = (ctypes.c_void_p * nt)(*[(o.data_ptr() if o is not None else None) for o in outs])
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().acfm_camera_pipeline_tables_backward(
+                ptrs, nt, F, _lib.ptr(fi), _lib.ptr(sel) if sel is not None else None, _lib.ptr(mf), _lib.ptr(tr),
+                _lib.ptr(g), R, N, decay, gptrs, _lib.cur_stream(g.device)), "acfm_camera_pipeline_tables_backward")
+        return (None,) * 6 + tuple(outs)
+
+
+def camera_pipeline_tables(tables, frames_idx, mirror_flag, transforms, scale_lr_decay=1.0, num_guesses=None,
+                           selected=None):
+    """Cameras [G*N,7] of all hypotheses straight from the per-hypothesis embedding tables ([frames,7] each,
+    mesh_net.py:436-444): the look-ups, the stack / top-k gather (main.py:551-570) and the decode / mirror / transform
+    chain (:572-584) in one kernel each way.  Row g*N + n reads tables[selected[g, n] if given else g][frames_idx[n]];
+    the backward returns dense [frames,7] gradients like nn.Embedding's."""
+    G = len(tables) if num_guesses is None else int(num_guesses)
+    return _CameraPipelineTables.apply(frames_idx, selected, mirror_flag, transforms, scale_lr_decay, G, *tables)
+
+
 class _CameraNormalize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw):

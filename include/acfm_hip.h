@@ -149,6 +149,19 @@ int acfm_camera_pipeline(const float* emb, const int64_t* mirror_flag, const flo
 int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, const float* transforms,
                                   const float* grad_cams, int R, int N, float scale_lr_decay, float* grad_emb,
                                   void* stream);
+/* the same straight from the per-hypothesis embedding tables (multiframe/nnutils/mesh_net.py:436-444: one
+ * nn.Embedding(frames, 7) per hypothesis; main.py:551-570 looks every one of them up and stacks / gathers the rows):
+ * row r = g*N + n reads tables[selected ? selected[r] : g][frames_idx[n]] (tables: HOST array of n_tables <= 32 device
+ * pointers to [n_frames,7] f32; selected [R] i64 or NULL: main.py:541-548's top-k choice).  backward: grad_tables[t]
+ * ([n_frames,7], HOST array of device pointers, NULL entries skipped) are WRITTEN -- zero except the rows the batch
+ * looked up, like nn.Embedding's dense gradient. */
+int acfm_camera_pipeline_tables(const void* const* tables, int n_tables, int n_frames, const int64_t* frames_idx,
+                                const int64_t* selected, const int64_t* mirror_flag, const float* transforms, int R,
+                                int N, float scale_lr_decay, float* cams, void* stream);
+int acfm_camera_pipeline_tables_backward(const void* const* tables, int n_tables, int n_frames, const int64_t* frames_idx,
+                                         const int64_t* selected, const int64_t* mirror_flag, const float* transforms,
+                                         const float* grad_cams, int R, int N, float scale_lr_decay,
+                                         void* const* grad_tables, void* stream);
 
 /* cam = (s, tx, ty, q / max(|q|, 1e-12)) of a raw [N,7] camera parameter: the per-iteration
  * torch.cat([scale, trans, F.normalize(quat)]) of the refinement loop (nnutils/predictor.py:301-308). */

@@ -600,6 +600,45 @@ def test_losses_with_references_shared_by_hypotheses(meshes):
 
 
 @pytest.mark.gpu
+def test_camera_pipeline_from_the_embedding_tables():
+    """ops.camera_pipeline_tables (look-ups of the G per-hypothesis tables + stack / top-k gather + decode + mirror +
+    transform, one kernel each way) == nn.Embedding look-ups, torch.stack / gather and ops.camera_pipeline (itself
+    compared with the oracle's restatement of main.py:97-138, 551-584 in test_gpu_composed), gradients included: dense
+    [frames,7] per table, zero outside the rows the batch looked up."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    Gall, F, B, T = 6, 40, 4, 2
+    N = B * T
+    tabs = [torch.randn(F, 7, generator=g).to(d).requires_grad_(True) for _ in range(Gall)]
+    refs = [t.detach().clone().requires_grad_(True) for t in tabs]
+    fi = torch.randperm(F, generator=g)[:N].reshape(B, T).to(d)
+    mf = torch.tensor([0, 1, 0, 0, 1, 1, 0, 1], device=d)
+    tr = torch.cat([torch.rand(N, 1, generator=g) + 0.5, torch.rand(N, 2, generator=g) - 0.5,
+                    (torch.rand(N, 1, generator=g) > 0.5).float()], 1).to(d)
+    wts = torch.randn(Gall * N, 7, generator=g).to(d)
+    for k, sel in ((Gall, None), (3, torch.stack([torch.randperm(Gall, generator=g)[:3] for _ in range(N)], 1)
+                                  .reshape(3, B, T).to(d))):
+        for t in tabs + refs:
+            t.grad = None
+        got = ops.camera_pipeline_tables(tabs, fi, mf, tr, 0.05, num_guesses=k, selected=sel)
+        cams = torch.stack([torch.nn.functional.embedding(fi, r) for r in refs])
+        if sel is not None:
+            cams = torch.gather(cams, 0, sel[..., None].expand(-1, -1, -1, 7))
+        want = ops.camera_pipeline(cams.reshape(k, -1, 7), mf, tr, 0.05)
+        assert torch.equal(got, want)
+        (got * wts[:k * N]).sum().backward()
+        (want * wts[:k * N]).sum().backward()
+        for a, b in zip(tabs, refs):
+            if b.grad is None:
+                assert a.grad is None or float(a.grad.abs().max()) == 0.0
+            else:
+                np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        ops.camera_pipeline_tables(tabs[:2], fi, mf, tr, 0.05, num_guesses=3)
+
+
+@pytest.mark.gpu
 def test_hypothesis_total_matches_the_torch_formula():
     """harness.hypothesis_total == the reference's per-hypothesis total + softmax weighting (multiframe/main.py:716-746:
     total = sum w_t T_t, probs = softmax(-total, 0).detach(), weighted = (total * probs).sum(0).mean()), the logged sums
