@@ -13,7 +13,8 @@ p = argparse.ArgumentParser()
 p.add_argument("--B", type=int, default=8); p.add_argument("--G", type=int, default=6)
 p.add_argument("--img", type=int, default=256); p.add_argument("--iters", type=int, default=10)
 p.add_argument("--mesh", default="horse"); p.add_argument("--tex", type=int, default=1)
-p.add_argument("--torch-profile", action="store_true"); p.add_argument("--graph", action="store_true"); p.add_argument("--series", type=int, default=0)
+p.add_argument("--torch-profile", action="store_true"); p.add_argument("--graph", action="store_true"); p.add_argument("--ops", action="store_true", help="eager step under torch.profiler: aten ops by count and shapes")
+p.add_argument("--series", type=int, default=0)
 a = p.parse_args()
 d = torch.device("cuda:0")
 m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz")); v, f = m[a.mesh + "_v"], m[a.mesh + "_f"]
@@ -49,6 +50,15 @@ else:
         loss, _ = step(batch, delta, textures=tex, imgs=imgs)
         loss.backward(); opt.step()
 for _ in range(3): one()
+if getattr(a, "ops", False) and not a.graph:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as pr:
+        one()
+    rows = [e for e in pr.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and
+            e.key.split("::")[1] in ("add", "add_", "mul", "mul_", "copy_", "clone", "fill_", "zero_", "zeros_like", "sum", "mean", "div", "neg", "repeat", "flip", "index_select", "embedding", "cat", "stack", "contiguous", "to", "_to_copy")]
+    for e in sorted(rows, key=lambda e: (-e.count, e.key)):
+        print("%3d x %-16s %s" % (e.count, e.key, str(e.input_shapes)[:150]))
+    sys.exit(0)
 if a.series:
     ts = []
     for _ in range(a.series):
