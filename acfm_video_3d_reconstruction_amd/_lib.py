@@ -66,6 +66,9 @@ SIGNATURES = {
     "acfm_combine_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "acfm_hypothesis_total": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acfm_hypothesis_total_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "acfm_texture_cycle_scratch_floats": (_sz, [_i, _i, _i, _i]),
+    "acfm_texture_cycle": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_texture_cycle_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_mask_losses_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_tex_mse": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -464,6 +464,81 @@ __global__ __launch_bounds__(256) void k_hyp_total_bwd(HypArgs a, int GN, int N,
   }
 }
 
+// ---- texture temporal-consistency term (multiframe/main.py:705-711), as written there ---------------------------
+// The atlases [B*T,F,R,R,3] are regrouped as [B,F,R,R,T,3], that buffer is RESHAPED to rows [-1,R,R] (the reference's
+// own regrouping of the trailing (R,T,3) block; reproduced, not "fixed"), and the loss is the mean L2 norm over the
+// last axis of the differences of neighbouring rows i, i+1.  X[m,i,j] below is element m R^2 + i R + j of the regrouped
+// buffer; cyc_src maps it back to its place in the atlases.  Forward: one thread per (m, i) writes the norm and a
+// partial sum per workgroup, a second small kernel adds the partials in order.  Backward: one thread per element
+// (every atlas entry is written exactly once: no atomics, no zero fill).
+struct CycDims { int B, T, F, R; };
+// (index arithmetic in 32 bits whenever the atlas batch has fewer than 2^31 entries: the decode below is five
+// divisions per element and 64-bit ones made these kernels 3x longer than the tensor traffic)
+template <class I>
+__device__ __forceinline__ I cyc_src(I q, const CycDims& d) {
+  const I c = q % 3; q /= 3;
+  const I t = q % (I)d.T; q /= (I)d.T;
+  const I r2 = q % (I)d.R; q /= (I)d.R;
+  const I r1 = q % (I)d.R; q /= (I)d.R;
+  const I f = q % (I)d.F; q /= (I)d.F;
+  const I b = q;
+  return ((((b * (I)d.T + t) * (I)d.F + f) * (I)d.R + r1) * (I)d.R + r2) * 3 + c;
+}
+template <class I>
+__global__ __launch_bounds__(256) void k_tex_cycle(const float* __restrict__ tex, CycDims d, size_t pairs,
+                                                   float* __restrict__ norms, float* __restrict__ partial) {
+  __shared__ float s_red[4];
+  const I p = (I)blockIdx.x * 256 + threadIdx.x;   // pair (m, i), i < R - 1
+  float nrm = 0.f;
+  if ((size_t)p < pairs) {
+    const I m = p / (I)(d.R - 1);
+    const I i = p % (I)(d.R - 1);
+    const I q0 = (m * (I)d.R + i) * (I)d.R;
+    float acc = 0.f;
+    for (int j = 0; j < d.R; ++j) {
+      const float df = tex[cyc_src<I>(q0 + (I)j, d)] - tex[cyc_src<I>(q0 + (I)d.R + (I)j, d)];
+      acc += df * df;
+    }
+    nrm = sqrtf(acc);
+    norms[p] = nrm;
+  }
+  const float v = wave_sum(nrm);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__global__ __launch_bounds__(256) void k_tex_cycle_finish(const float* __restrict__ partial, int nblocks, float scale,
+                                                          float* __restrict__ out) {
+  __shared__ float s_red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+  const float v = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * scale;
+}
+template <class I>
+__global__ __launch_bounds__(256) void k_tex_cycle_bwd(const float* __restrict__ tex, const float* __restrict__ norms,
+                                                       const float* __restrict__ go, CycDims d, size_t total, float scale,
+                                                       float* __restrict__ grad) {
+  const I q = (I)blockIdx.x * 256 + threadIdx.x;   // element (m, i, j) of the regrouped buffer
+  if ((size_t)q >= total) return;
+  const I i = (q / (I)d.R) % (I)d.R;
+  const I m = q / ((I)d.R * (I)d.R);
+  const I src = cyc_src<I>(q, d);
+  const float x = tex[src];
+  float g = 0.f;
+  if (i + 1 < (I)d.R) {         // pair (m, i): d norm / d x = (x - x_below) / norm
+    const float n = norms[m * (I)(d.R - 1) + i];
+    if (n > 0.f) g += (x - tex[cyc_src<I>(q + (I)d.R, d)]) / n;
+  }
+  if (i > 0) {                  // pair (m, i - 1): d norm / d x = -(x_above - x) / norm
+    const float n = norms[m * (I)(d.R - 1) + i - 1];
+    if (n > 0.f) g -= (tex[cyc_src<I>(q - (I)d.R, d)] - x) / n;
+  }
+  grad[src] = g * go[0] * scale;
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -598,6 +673,45 @@ int acfm_hypothesis_total_backward(const float* grad_weighted, const float* prob
   const int GN = G * N;
   hipLaunchKernelGGL(k_hyp_total_bwd, dim3((GN + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, GN, N,
                      grad_weighted, probs);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+size_t acfm_texture_cycle_scratch_floats(int B, int T, int F, int R) {
+  if (B <= 0 || T <= 0 || F <= 0 || R < 2) return 0;
+  const size_t total = (size_t)B * T * F * R * R * 3, pairs = total / ((size_t)R * R) * (R - 1);
+  return pairs + (pairs + 255) / 256;
+}
+
+int acfm_texture_cycle(const float* textures, int B, int T, int F, int R, float* scratch, float* loss, void* stream) {
+  if (!textures || !scratch || !loss || B <= 0 || T <= 0 || F <= 0 || R < 2) return ACFM_E_BADARG;
+  const size_t total = (size_t)B * T * F * R * R * 3, pairs = total / ((size_t)R * R) * (R - 1);
+  const size_t nblocks = (pairs + 255) / 256;
+  if (nblocks > 0x7fffffffull) return ACFM_E_BADARG;
+  const CycDims d = {B, T, F, R};
+  hipStream_t st = (hipStream_t)stream;
+  if (total < 0x7fffffffull)
+    hipLaunchKernelGGL(k_tex_cycle<unsigned>, dim3((unsigned)nblocks), dim3(256), 0, st, textures, d, pairs, scratch, scratch + pairs);
+  else
+    hipLaunchKernelGGL(k_tex_cycle<size_t>, dim3((unsigned)nblocks), dim3(256), 0, st, textures, d, pairs, scratch, scratch + pairs);
+  hipLaunchKernelGGL(k_tex_cycle_finish, dim3(1), dim3(256), 0, st, scratch + pairs, (int)nblocks, 1.0f / (float)pairs, loss);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_texture_cycle_backward(const float* textures, const float* scratch, const float* grad_loss, int B, int T, int F,
+                                int R, float* grad_textures, void* stream) {
+  if (!textures || !scratch || !grad_loss || !grad_textures || B <= 0 || T <= 0 || F <= 0 || R < 2) return ACFM_E_BADARG;
+  const size_t total = (size_t)B * T * F * R * R * 3, pairs = total / ((size_t)R * R) * (R - 1);
+  const size_t nblocks = (total + 255) / 256;
+  if (nblocks > 0x7fffffffull) return ACFM_E_BADARG;
+  const CycDims d = {B, T, F, R};
+  if (total < 0x7fffffffull)
+    hipLaunchKernelGGL(k_tex_cycle_bwd<unsigned>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, textures, scratch,
+                       grad_loss, d, total, 1.0f / (float)pairs, grad_textures);
+  else
+    hipLaunchKernelGGL(k_tex_cycle_bwd<size_t>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, textures, scratch,
+                       grad_loss, d, total, 1.0f / (float)pairs, grad_textures);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -36,6 +36,9 @@ def texture_cycle_loss(textures, num_frames):
     the per-frame atlases [B*T,F,R,R,3] are regrouped as [B,F,R,R,T,3] and then RESHAPED to [-1,R,R] -- the
     reference's own regrouping of the trailing (R, T, 3) block, reproduced as written, not "fixed" -- and the
     loss is the mean L2 norm (over the last axis) of the differences of neighbours along axis 1."""
+    if textures.is_cuda:      # the same regrouping and norms in two launches forward, one backward (csrc/acfm_loss.hip)
+        from . import ops
+        return ops.texture_cycle(textures, num_frames)
     t_c = textures.reshape(-1, num_frames, *textures.shape[1:]).permute(0, 2, 3, 4, 1, 5)
     t_c = t_c.reshape(-1, t_c.shape[2], t_c.shape[3])
     return torch.norm(t_c[:, :-1] - t_c[:, 1:], p=2, dim=-1).mean()

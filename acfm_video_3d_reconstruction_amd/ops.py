@@ -1009,6 +1009,43 @@ def hypothesis_total(terms, weights, G, N, aux_group=None, aux_weights=None):
     return _HypTotal.apply(tuple(float(w) for w in weights), ag, aw, int(G), int(N), *terms)
 
 
+class _TexCycle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, textures, T):
+        _lib.require_gpu(textures)
+        x = _f32c(textures)
+        if x.dim() != 5 or x.shape[2] != x.shape[3] or x.shape[4] != 3 or x.shape[0] % int(T) != 0 or x.shape[2] < 2:
+            raise ValueError("texture_cycle: atlases [B*T,F,R,R,3] with R >= 2, got %s (T = %d)" % (tuple(x.shape), T))
+        B, F, R = x.shape[0] // int(T), x.shape[1], x.shape[2]
+        lib = _lib.lib()
+        scratch = torch.empty(lib.acfm_texture_cycle_scratch_floats(B, int(T), F, R), dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.acfm_texture_cycle(_lib.ptr(x), B, int(T), F, R, _lib.ptr(scratch), _lib.ptr(loss),
+                                              _lib.cur_stream(x.device)), "acfm_texture_cycle")
+        ctx.save_for_backward(x, scratch)
+        ctx.cfg = (B, int(T), F, R, textures.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        x, scratch = ctx.saved_tensors
+        B, T, F, R, dt = ctx.cfg
+        g = _f32c(go).reshape(1)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().acfm_texture_cycle_backward(_lib.ptr(x), _lib.ptr(scratch), _lib.ptr(g), B, T, F, R,
+                                                              _lib.ptr(gx), _lib.cur_stream(x.device)),
+                       "acfm_texture_cycle_backward")
+        return (gx if dt == torch.float32 else gx.to(dt)), None
+
+
+def texture_cycle(textures, num_frames):
+    """The texture temporal-consistency term of ShapeTrainer.forward as written there (multiframe/main.py:705-711):
+    atlases [B*T,F,R,R,3] -> scalar; two launches forward, one backward (fixed summation order)."""
+    return _TexCycle.apply(textures, int(num_frames))
+
+
 # ------------------------------------------------------------------------------ boundary loss
 def visible_vertices(pix_to_face, faces, nv):
     """[N,H,W,K] i64 (slot 0 read) x faces [N,F,3] -> uint8 [N,nv].  A pix_to_face tensor that

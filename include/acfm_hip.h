@@ -362,6 +362,17 @@ int acfm_hypothesis_total(const void* const* terms, const float* weights, const 
 int acfm_hypothesis_total_backward(const float* grad_weighted, const float* probs, const float* weights, int nterms,
                                    int G, int N, void* const* grads, void* stream);
 
+/* ---- texture temporal-consistency term ------------------------------------------------------------
+ * replaces multiframe/main.py:705-711 as written there: the per-frame atlases textures [B*T,F,R,R,3] regrouped as
+ * [B,F,R,R,T,3], that buffer reshaped to rows [-1,R,R], loss = mean over (row block m, i < R-1) of the L2 norm over
+ * j of X[m,i,j] - X[m,i+1,j] (zero norms contribute no gradient, as torch.norm's backward).
+ * scratch: acfm_texture_cycle_scratch_floats(B,T,F,R) floats (the norms, kept for the backward, + partial sums);
+ * any B, T, F; R >= 2.  Sums in a fixed order: reproducible. */
+size_t acfm_texture_cycle_scratch_floats(int B, int T, int F, int R);
+int acfm_texture_cycle(const float* textures, int B, int T, int F, int R, float* scratch, float* loss, void* stream);
+int acfm_texture_cycle_backward(const float* textures, const float* scratch, const float* grad_loss, int B, int T, int F,
+                                int R, float* grad_textures, void* stream);
+
 /* ---- fused silhouette losses ---------------------------------------------------------
  * replaces loss_utils.l1_loss / iou / iou_loss / edt_loss with reduce=False
  * (multiframe/nnutils/loss_utils.py:18-32, 72-77, 245-253) in one pass over the mask:

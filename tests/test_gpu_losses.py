@@ -639,6 +639,28 @@ def test_camera_pipeline_from_the_embedding_tables():
 
 
 @pytest.mark.gpu
+def test_texture_cycle_term_vs_the_oracle_restatement():
+    """ops.texture_cycle == oracle.texture_cycle_loss (main.py:705-711 as written: regroup, reshape to [-1,R,R], mean L2
+    norm of neighbouring rows) in float64, value and gradient; repeated entries (zero norms) give no gradient."""
+    from acfm_video_3d_reconstruction_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for B, T, F, R in ((1, 2, 3, 2), (2, 2, 7, 6), (3, 3, 5, 4), (8, 2, 1280, 6)):
+        x = torch.rand(B * T, F, R, R, 3, generator=g)
+        x[0, 0] = 0.25                                   # a constant atlas face: some zero norms
+        a = x.to(d).requires_grad_(True)
+        la = ops.texture_cycle(a, T)
+        b = x.double().requires_grad_(True)
+        lb = O.texture_cycle_loss(b, T)
+        np.testing.assert_allclose(la.item(), lb.item(), rtol=2e-6)
+        (la * 3.0).backward()
+        (lb * 3.0).backward()
+        gb = torch.nan_to_num(b.grad, nan=0.0)           # (float64 torch.norm backward at 0: masked to 0 as well)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gb.numpy(), rtol=1e-4, atol=1e-9)
+        assert torch.equal(ops.texture_cycle(a, T), la)  # fixed summation order
+
+
+@pytest.mark.gpu
 def test_hypothesis_total_matches_the_torch_formula():
     """harness.hypothesis_total == the reference's per-hypothesis total + softmax weighting (multiframe/main.py:716-746:
     total = sum w_t T_t, probs = softmax(-total, 0).detach(), weighted = (total * probs).sum(0).mean()), the logged sums
