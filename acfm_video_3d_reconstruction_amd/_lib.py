@@ -31,6 +31,8 @@ SIGNATURES = {
     "acfm_correlation_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_of_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_of_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acfm_of_loss_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "acfm_of_loss_shared_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_camera_pipeline": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_pipeline_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_pipeline_tables": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),

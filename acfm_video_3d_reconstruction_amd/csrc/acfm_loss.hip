@@ -293,7 +293,15 @@ __global__ __launch_bounds__(256) void k_bds_loss_bwd(const float* __restrict__ 
 // (grid_sample, mode nearest, align_corners False, zero padding), predicted flow = pixel
 // displacement of the vertex between frame k-1 and k, both counted where the vertex is visible in
 // frame k and the GT flow is non-zero;  loss[c,k-1] = sum |gt - pred|_1 / H / (count + 1).
-__device__ __forceinline__ bool of_term(const float* __restrict__ proj, const float* __restrict__ flows,
+// Where the GT flow of (clip c, frame k) comes from: flows holds `clips` clips of T frames (clip c reads c % clips:
+// the G hypotheses of a clip share its data), frame k reads T-1-k if flip_t (main.py:680: torch.flip(flows, dims=[1])),
+// and the value is multiplied by masks[(c % clips) T + k] at the same pixel if masks is given (main.py:680-681).
+struct OfSrc {
+  const float* flows;
+  const float* masks;
+  int clips, flip_t;
+};
+__device__ __forceinline__ bool of_term(const float* __restrict__ proj, const OfSrc& src,
                                         const uint8_t* __restrict__ vis, int c, int k, int v, int T, int V,
                                         int H, int W, float& dx, float& dy) {
   const size_t fk = (size_t)c * T + k;
@@ -303,8 +311,14 @@ __device__ __forceinline__ bool of_term(const float* __restrict__ proj, const fl
   const float ixf = rintf(((x + 1.0f) * (float)W - 1.0f) / 2.0f), iyf = rintf(((y + 1.0f) * (float)H - 1.0f) / 2.0f);
   float gx = 0.f, gy = 0.f;
   if (ixf >= 0.f && ixf <= (float)(W - 1) && iyf >= 0.f && iyf <= (float)(H - 1)) {
-    const float* g = flows + ((fk * H + (int)iyf) * (size_t)W + (int)ixf) * 2;
+    const size_t cs = (size_t)(c % src.clips) * T;
+    const size_t pixel = (size_t)(int)iyf * W + (int)ixf;
+    const float* g = src.flows + ((cs + (src.flip_t ? T - 1 - k : k)) * H * (size_t)W + pixel) * 2;
     gx = g[0]; gy = g[1];
+    if (src.masks) {
+      const float m = src.masks[(cs + k) * H * (size_t)W + pixel];
+      gx *= m; gy *= m;
+    }
   }
   const bool keep = (fabsf(gx) + fabsf(gy) != 0.0f) && vis[fk * V + v] != 0;
   const float fw = (float)W;
@@ -314,7 +328,7 @@ __device__ __forceinline__ bool of_term(const float* __restrict__ proj, const fl
   return keep;
 }
 
-__global__ __launch_bounds__(LTPB) void k_of_loss(const float* __restrict__ proj, const float* __restrict__ flows,
+__global__ __launch_bounds__(LTPB) void k_of_loss(const float* __restrict__ proj, OfSrc flows,
                                                   const uint8_t* __restrict__ vis, int T, int V, int H, int W,
                                                   float* __restrict__ loss, float* __restrict__ count) {
   __shared__ float s_red[4][2];
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(LTPB) void k_of_loss(const float* __restrict__ proj
   }
 }
 
-__global__ __launch_bounds__(LTPB) void k_of_loss_bwd(const float* __restrict__ proj, const float* __restrict__ flows,
+__global__ __launch_bounds__(LTPB) void k_of_loss_bwd(const float* __restrict__ proj, OfSrc flows,
                                                       const uint8_t* __restrict__ vis, const float* __restrict__ count,
                                                       const float* __restrict__ gl, int T, int V, int H, int W,
                                                       float* __restrict__ gproj) {
@@ -761,29 +775,42 @@ int acfm_bds_loss_backward(const float* verts_xy, const float* bds, const int32_
   return ACFM_OK;
 }
 
-int acfm_of_loss(const float* proj, const float* flows, const uint8_t* vis, int B, int T, int V, int H, int W,
-                 float* loss, float* count, void* stream) {
+int acfm_of_loss_shared(const float* proj, const float* flows, const float* masks, const uint8_t* vis, int B, int T,
+                        int V, int H, int W, int clips, int flip_t, float* loss, float* count, void* stream) {
   if (!proj || !flows || !vis || !loss || !count || B <= 0 || B > 65535 || T < 2 || T > 65535 || V <= 0 || H <= 0 ||
-      W <= 0)
+      W <= 0 || clips <= 0 || B % clips != 0)
     return ACFM_E_BADARG;
-  hipLaunchKernelGGL(k_of_loss, dim3(T - 1, B), dim3(LTPB), 0, (hipStream_t)stream, proj, flows, vis, T, V, H, W,
+  const OfSrc src = {flows, masks, clips, flip_t ? 1 : 0};
+  hipLaunchKernelGGL(k_of_loss, dim3(T - 1, B), dim3(LTPB), 0, (hipStream_t)stream, proj, src, vis, T, V, H, W,
                      loss, count);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
 
-int acfm_of_loss_backward(const float* proj, const float* flows, const uint8_t* vis, const float* count,
-                          const float* grad_loss, int B, int T, int V, int H, int W, float* grad_proj,
-                          void* stream) {
+int acfm_of_loss_shared_backward(const float* proj, const float* flows, const float* masks, const uint8_t* vis,
+                                 const float* count, const float* grad_loss, int B, int T, int V, int H, int W, int clips,
+                                 int flip_t, float* grad_proj, void* stream) {
   if (!proj || !flows || !vis || !count || !grad_loss || !grad_proj || B <= 0 || B > 65535 || T < 2 || T > 65535 ||
-      V <= 0 || H <= 0 || W <= 0)
+      V <= 0 || H <= 0 || W <= 0 || clips <= 0 || B % clips != 0)
     return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(grad_proj, sizeof(float) * 3 * (size_t)B * T * V, st) != ACFM_OK) return ACFM_E_LAUNCH;
-  hipLaunchKernelGGL(k_of_loss_bwd, dim3((V + LTPB - 1) / LTPB, T - 1, B), dim3(LTPB), 0, st, proj, flows, vis, count,
+  const OfSrc src = {flows, masks, clips, flip_t ? 1 : 0};
+  hipLaunchKernelGGL(k_of_loss_bwd, dim3((V + LTPB - 1) / LTPB, T - 1, B), dim3(LTPB), 0, st, proj, src, vis, count,
                      grad_loss, T, V, H, W, grad_proj);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
+}
+
+int acfm_of_loss(const float* proj, const float* flows, const uint8_t* vis, int B, int T, int V, int H, int W,
+                 float* loss, float* count, void* stream) {
+  return acfm_of_loss_shared(proj, flows, nullptr, vis, B, T, V, H, W, B, 0, loss, count, stream);
+}
+
+int acfm_of_loss_backward(const float* proj, const float* flows, const uint8_t* vis, const float* count,
+                          const float* grad_loss, int B, int T, int V, int H, int W, float* grad_proj,
+                          void* stream) {
+  return acfm_of_loss_shared_backward(proj, flows, nullptr, vis, count, grad_loss, B, T, V, H, W, B, 0, grad_proj, stream);
 }
 
 }  // extern "C"

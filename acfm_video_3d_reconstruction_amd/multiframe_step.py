@@ -143,9 +143,14 @@ class MultiframeStep(nn.Module):
             return torch.zeros(1, device=pred_v.device)
         T = o.num_frames
         B = batch["masks"].shape[0] // T
+        faces_of = self.faces1[None, None].expand(G * B, T, -1, -1)
+        if pred_v.is_cuda:    # main.py:676-686's flip / mask / repeat(G) of the flow images happen inside the loss kernel
+            of_loss = loss_utils.optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, batch["optical_flows"],
+                                                   self.of_renderer, pix_to_face=None, reduce=False, loss_only=True,
+                                                   flow_masks=batch["masks"], flip_t=True)
+            return of_loss.reshape(G, -1).repeat(1, T).reshape(G, -1)    # main.py:684-686
         masks_of = batch["masks"].reshape(B, T, *batch["masks"].shape[1:])
         flows = (torch.flip(batch["optical_flows"], dims=[1]) * masks_of[..., None]).repeat(G, 1, 1, 1, 1)
-        faces_of = self.faces1[None, None].expand(G * B, T, -1, -1)
         of_loss = loss_utils.optical_flow_loss(pred_v.reshape(G * B, T, -1, 3), faces_of, cam, flows,
                                                self.of_renderer, pix_to_face=None, reduce=False, loss_only=True)
         return of_loss.reshape(G, -1).repeat(1, T).reshape(G, -1)    # main.py:684-686

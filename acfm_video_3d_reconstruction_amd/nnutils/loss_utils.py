@@ -265,11 +265,14 @@ class TexCycle(nn.Module):
         return F.mse_loss(mean_flow * seen, prob * seen), mean_flow[0, :10]
 
 
-def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True, loss_only=False):
+def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=True, loss_only=False,
+                      flow_masks=None, flip_t=False):
     """loss_utils.py:419-474.  meshes [b,t,V,3], faces [b,t,F,3], cams [b*t,7],
     flows [b,t,H,W,2]; renderer: an OF_NeuralRenderer-like object (proj_fn + __call__).
     loss_only=True (not in the reference): return just the loss, from one fused kernel
-    (ops.of_loss), instead of the 5-tuple with the per-vertex intermediates."""
+    (ops.of_loss), instead of the 5-tuple with the per-vertex intermediates; with it, flows may be the data loader's
+    [clips,t,H,W,2] for b = G*clips rendered clips, flipped in time (flip_t) and masked (flow_masks [clips*t,H,W]) inside
+    the kernel instead of by main.py:676-686's flip / multiply / repeat(G)."""
     H, W = flows.shape[2:4]
     b, t, nv, _ = meshes.shape
     bt = b * t
@@ -282,8 +285,11 @@ def optical_flow_loss(meshes, faces, cams, flows, renderer, pix_to_face, reduce=
             pix_to_face = pix_to_face[..., :1]
         visible_vertices = ops.visible_vertices(pix_to_face, faces_bt, nv).reshape(b, t, nv)
     if loss_only and predicted_points.is_cuda:
-        loss = ops.of_loss(predicted_points.reshape(bt, nv, 3), flows.reshape(bt, H, W, -1), visible_vertices, b, t)
+        loss = ops.of_loss(predicted_points.reshape(bt, nv, 3), flows.reshape(-1, H, W, 2), visible_vertices, b, t,
+                           masks=flow_masks, flip_t=flip_t)
         return loss.sum() if reduce else loss
+    if flow_masks is not None or flip_t or flows.shape[0] != b:
+        raise ValueError("optical_flow_loss: shared / flipped / masked flows need loss_only=True on the GPU")
 
     xy = predicted_points[..., :2]                                            # [bt, V, 2] in [-1, 1]
     # GT flow at each projected vertex: nearest pixel (:449-452)

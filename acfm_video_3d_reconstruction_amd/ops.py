@@ -421,42 +421,52 @@ def camera_normalize(cam_raw):
 # ------------------------------------------------------------------------------ optical flow
 class _OFLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, proj, flows, vis, B, T):
+    def forward(ctx, proj, flows, vis, B, T, masks, flip_t):
         _lib.require_gpu(proj, flows, vis)
         p, fl = _f32c(proj), _f32c(flows)
         V = p.shape[-2]
         H, W = fl.shape[-3], fl.shape[-2]
         vi = vis.detach().reshape(-1, V).to(torch.uint8).contiguous()
-        if p.numel() != B * T * V * 3 or fl.numel() != B * T * H * W * 2 or vi.shape[0] != B * T:
-            raise ValueError("of_loss: proj %s flows %s vis %s do not match B=%d T=%d"
-                             % (tuple(p.shape), tuple(fl.shape), tuple(vi.shape), B, T))
+        clips = fl.numel() // (T * H * W * 2)
+        mk = None if masks is None else _f32c(masks)
+        if p.numel() != B * T * V * 3 or clips < 1 or fl.numel() != clips * T * H * W * 2 or B % clips != 0 or \
+                vi.shape[0] != B * T or (mk is not None and mk.numel() != clips * T * H * W):
+            raise ValueError("of_loss: proj %s flows %s vis %s masks %s do not match B=%d T=%d"
+                             % (tuple(p.shape), tuple(fl.shape), tuple(vi.shape),
+                                None if mk is None else tuple(mk.shape), B, T))
         loss = torch.empty((B, T - 1), dtype=torch.float32, device=p.device)
         cnt = torch.empty((B, T - 1), dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().acfm_of_loss(_lib.ptr(p), _lib.ptr(fl), _lib.ptr(vi), B, T, V, H, W,
-                                               _lib.ptr(loss), _lib.ptr(cnt), _lib.cur_stream(p.device)),
-                       "acfm_of_loss")
-        ctx.save_for_backward(p, fl, vi, cnt)
-        ctx.dims = (B, T, V, H, W)
+            _lib.check(_lib.lib().acfm_of_loss_shared(_lib.ptr(p), _lib.ptr(fl), _lib.ptr(mk) if mk is not None else None,
+                                                      _lib.ptr(vi), B, T, V, H, W, clips, int(bool(flip_t)),
+                                                      _lib.ptr(loss), _lib.ptr(cnt), _lib.cur_stream(p.device)),
+                       "acfm_of_loss_shared")
+        ctx.save_for_backward(p, fl, vi, cnt) if mk is None else ctx.save_for_backward(p, fl, vi, cnt, mk)
+        ctx.dims = (B, T, V, H, W, clips, int(bool(flip_t)), mk is not None)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        p, fl, vi, cnt = ctx.saved_tensors
-        B, T, V, H, W = ctx.dims
+        B, T, V, H, W, clips, flip_t, has_m = ctx.dims
+        p, fl, vi, cnt = ctx.saved_tensors[:4]
+        mk = ctx.saved_tensors[4] if has_m else None
         g = _f32c(g)
         gp = torch.empty_like(p)
         with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().acfm_of_loss_backward(_lib.ptr(p), _lib.ptr(fl), _lib.ptr(vi), _lib.ptr(cnt),
-                                                        _lib.ptr(g), B, T, V, H, W, _lib.ptr(gp),
-                                                        _lib.cur_stream(p.device)), "acfm_of_loss_backward")
-        return gp, None, None, None, None
+            _lib.check(_lib.lib().acfm_of_loss_shared_backward(
+                _lib.ptr(p), _lib.ptr(fl), _lib.ptr(mk) if mk is not None else None, _lib.ptr(vi), _lib.ptr(cnt),
+                _lib.ptr(g), B, T, V, H, W, clips, flip_t, _lib.ptr(gp), _lib.cur_stream(p.device)),
+                "acfm_of_loss_shared_backward")
+        return gp, None, None, None, None, None, None
 
 
-def of_loss(proj, flows, vis, B, T):
+def of_loss(proj, flows, vis, B, T, masks=None, flip_t=False):
     """Optical-flow loss per clip and frame pair [B,T-1] from projected vertices [B*T,V,3], GT flow
-    images [B*T,H,W,2] and the visible-vertex bitmap [B*T,V] (loss_utils.py:445-474, one kernel)."""
-    return _OFLoss.apply(proj, flows, vis, int(B), int(T))
+    images and the visible-vertex bitmap [B*T,V] (loss_utils.py:445-474, one kernel).  flows: [B*T,H,W,2], or
+    [clips*T,H,W,2] with B a multiple of clips (rendered clip c reads clip c % clips: the hypotheses of a clip share its
+    data); flip_t: frame k reads frame T-1-k; masks [clips*T,H,W]: the flow is multiplied by the mask of frame k at the
+    sampled pixel -- i.e. main.py:676-686's flip / mask / repeat(G) of the flow images without materialising them."""
+    return _OFLoss.apply(proj, flows, vis, int(B), int(T), masks, bool(flip_t))
 
 
 # ------------------------------------------------------------------------------ correlation

@@ -135,6 +135,15 @@ int acfm_of_loss(const float* proj, const float* flows, const uint8_t* vis, int 
 int acfm_of_loss_backward(const float* proj, const float* flows, const uint8_t* vis, const float* count,
                           const float* grad_loss, int B, int T, int V, int H, int W, float* grad_proj,
                           void* stream);
+/* the same with the GT flows as the data loader holds them (multiframe/main.py:676-686 flips them in time, masks
+ * them and repeats them for the G hypotheses every step; the loss reads V pixels per frame): flows [clips,T,H,W,2],
+ * clip c of the B = G*clips rendered ones reads clip c % clips, frame k reads frame T-1-k if flip_t, and the value is
+ * multiplied by masks [clips*T,H,W] at the same pixel of frame k if masks is not NULL. */
+int acfm_of_loss_shared(const float* proj, const float* flows, const float* masks, const uint8_t* vis, int B, int T,
+                        int V, int H, int W, int clips, int flip_t, float* loss, float* count, void* stream);
+int acfm_of_loss_shared_backward(const float* proj, const float* flows, const float* masks, const uint8_t* vis,
+                                 const float* count, const float* grad_loss, int B, int T, int V, int H, int W, int clips,
+                                 int flip_t, float* grad_proj, void* stream);
 
 /* ---- camera hypothesis pipeline --------------------------------------------------------
  * replaces the camera decode + mirror_cameras + transform_cameras chain of ShapeTrainer.forward /

@@ -533,6 +533,24 @@ def test_optical_flow_loss_fused_vs_torch_path(meshes):
         np.testing.assert_allclose(ca.grad.cpu().numpy(), cb.grad.cpu().numpy(), rtol=1e-3,
                                    atol=1e-4 * float(cb.grad.abs().max()))
         assert float(lb.abs().sum()) > 0
+        # the data loader's flows, flipped in time, masked and shared by G hypotheses INSIDE the kernel
+        # == main.py:676-686's flip / multiply / repeat(G) materialised, bit for bit
+        G = 2
+        masks = torch.tensor(rng.uniform(size=(b * t, H, H)) > 0.3, dtype=torch.float32, device=d)
+        prep = (torch.flip(flows, dims=[1]) * masks.reshape(b, t, H, H)[..., None]).repeat(G, 1, 1, 1, 1)
+        vg = verts.repeat(G, 1, 1, 1) + 0.001 * torch.randn(G * b, t, *verts.shape[2:], device=d)
+        cg, fg = cams.repeat(G, 1), faces.repeat(G, 1, 1, 1)
+        v1, c1 = vg.clone().requires_grad_(True), cg.clone().requires_grad_(True)
+        l1 = L.optical_flow_loss(v1, fg, c1, flows, ren, None, reduce=False, loss_only=True, flow_masks=masks, flip_t=True)
+        v2, c2 = vg.clone().requires_grad_(True), cg.clone().requires_grad_(True)
+        l2 = L.optical_flow_loss(v2, fg, c2, prep, ren, None, reduce=False, loss_only=True)
+        assert torch.equal(l1, l2) and l1.shape == (G * b, t - 1)
+        l1.sum().backward()
+        l2.sum().backward()
+        np.testing.assert_allclose(v1.grad.cpu().numpy(), v2.grad.cpu().numpy(), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(c1.grad.cpu().numpy(), c2.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        L.optical_flow_loss(va, faces, ca, flows, ren, None, reduce=False, flip_t=True)
 
 
 def test_correlation_cost_volume_vs_oracle():
