@@ -35,6 +35,7 @@ SIGNATURES = {
     "acfm_of_loss_shared_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_camera_pipeline": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_pipeline_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "acfm_camera_mirror": (_i, [_vp, _i, _vp, _vp]),
     "acfm_camera_pipeline_tables": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_pipeline_tables_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "acfm_camera_normalize": (_i, [_vp, _i, _vp, _vp]),

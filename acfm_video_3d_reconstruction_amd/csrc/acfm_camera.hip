@@ -195,6 +195,22 @@ __global__ void k_camera_normalize_bwd(const float* __restrict__ raw, const floa
   }
 }
 
+// pose of the horizontally flipped image of an already decoded camera (multiframe/main.py:97-125 with flag 1):
+// (s, tx, ty, q) -> (s, -tx, ty, standardize(q_y(pi) * standardize(q))), q_y(pi) = (0, 0, 1, 0); one thread per camera.
+// (The reference's chain of pytorch3d.transforms calls is ~35 elementwise launches on [R,4] tensors.)
+__global__ void k_camera_mirror(const float* __restrict__ cams, int R, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* c = cams + (size_t)r * 7;
+  const float sg = c[3] < 0.0f ? -1.0f : 1.0f;
+  const float b0 = sg * c[3], b1 = sg * c[4], b2 = sg * c[5], b3 = sg * c[6];
+  const float raw[4] = {-b2, b3, b0, -b1};
+  const float s2 = raw[0] < 0.0f ? -1.0f : 1.0f;
+  float* o = out + (size_t)r * 7;
+  o[0] = c[0]; o[1] = -c[1]; o[2] = c[2];
+  o[3] = s2 * raw[0]; o[4] = s2 * raw[1]; o[5] = s2 * raw[2]; o[6] = s2 * raw[3];
+}
+
 }  // namespace acfm
 
 using namespace acfm;
@@ -256,6 +272,13 @@ int acfm_camera_pipeline_tables_backward(const void* const* tables, int n_tables
   }
   hipLaunchKernelGGL(k_camera_bwd_tables, dim3((R + 127) / 128), dim3(128), 0, st, tb, frames_idx, selected,
                      mirror_flag, transforms, grad_cams, R, N, scale_lr_decay);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
+
+int acfm_camera_mirror(const float* cams, int R, float* out, void* stream) {
+  if (!cams || !out || R <= 0) return ACFM_E_BADARG;
+  hipLaunchKernelGGL(k_camera_mirror, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, cams, R, out);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -258,7 +258,11 @@ class MultiframeStep(nn.Module):
             tex_pred, _, _ = self.tex_renderer(pred_v.detach(), faces, cam, textures=tex)
             # main.py:97-110 (mirror_sample) without flipping the rendered masks nobody reads
             imgs_f, masks_f = torch.flip(imgs, dims=(3,)), torch.flip(batch["masks"], dims=(2,))
-            cam_f = harness._mirrored_pose(cam)
+            if cam.is_cuda:   # one kernel instead of ~35 quaternion launches; the texture render sends its cameras no gradient
+                from . import ops
+                cam_f = ops.camera_mirror(cam)
+            else:
+                cam_f = harness._mirrored_pose(cam)
             tex_pred_f, _, _ = self.tex_renderer(pred_v.detach(), faces, cam_f, textures=tex)
             tl += [loss_utils.masked_texture_mse(tex_pred, imgs, batch["masks"]),
                    loss_utils.masked_texture_mse(tex_pred_f, imgs_f, masks_f)]          # mse = their mean

@@ -388,6 +388,18 @@ def camera_pipeline_tables(tables, frames_idx, mirror_flag, transforms, scale_lr
     return _CameraPipelineTables.apply(frames_idx, selected, mirror_flag, transforms, scale_lr_decay, G, *tables)
 
 
+def camera_mirror(cams):
+    """Decoded cameras [R,7] -> the pose of the horizontally flipped image (multiframe/main.py:97-125 with the flag
+    set), one kernel; no gradient (the texture render it feeds sends none to its cameras)."""
+    _lib.require_gpu(cams)
+    c = _f32c(cams.detach()).reshape(-1, 7)
+    out = torch.empty_like(c)
+    with torch.cuda.device(c.device):
+        _lib.check(_lib.lib().acfm_camera_mirror(_lib.ptr(c), c.shape[0], _lib.ptr(out), _lib.cur_stream(c.device)),
+                   "acfm_camera_mirror")
+    return out
+
+
 class _CameraNormalize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw):

@@ -158,6 +158,10 @@ int acfm_camera_pipeline(const float* emb, const int64_t* mirror_flag, const flo
 int acfm_camera_pipeline_backward(const float* emb, const int64_t* mirror_flag, const float* transforms,
                                   const float* grad_cams, int R, int N, float scale_lr_decay, float* grad_emb,
                                   void* stream);
+/* pose of the horizontally flipped image of decoded cameras [R,7] (multiframe/main.py:97-125 with the flag set; the
+ * texture branch renders every frame once more under it, main.py:627-636): (s, -tx, ty, standardize(q_y(pi) *
+ * standardize(q))).  Forward only: the texture render sends no gradient to its cameras. */
+int acfm_camera_mirror(const float* cams, int R, float* out, void* stream);
 /* the same straight from the per-hypothesis embedding tables (multiframe/nnutils/mesh_net.py:436-444: one
  * nn.Embedding(frames, 7) per hypothesis; main.py:551-570 looks every one of them up and stacks / gathers the rows):
  * row r = g*N + n reads tables[selected ? selected[r] : g][frames_idx[n]] (tables: HOST array of n_tables <= 32 device

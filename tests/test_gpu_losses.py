@@ -654,6 +654,13 @@ def test_camera_pipeline_from_the_embedding_tables():
                 np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
     with pytest.raises(ValueError):
         ops.camera_pipeline_tables(tabs[:2], fi, mf, tr, 0.05, num_guesses=3)
+    # the mirrored pose of decoded cameras (what the texture branch renders under): one kernel == harness's chain of
+    # pytorch3d.transforms calls (property-tested on the CPU, and against the oracle inside the composed tests)
+    from acfm_video_3d_reconstruction_amd import harness
+    cams = ops.camera_pipeline_tables(tabs, fi, mf, tr, 0.05).detach()
+    cams[::3, 3:] *= -1.0
+    np.testing.assert_allclose(ops.camera_mirror(cams).cpu().numpy(), harness._mirrored_pose(cams).cpu().numpy(),
+                               rtol=0, atol=0)
 
 
 @pytest.mark.gpu
