@@ -23,7 +23,7 @@ def mesh_laplacian_smoothing(meshes, method: str = "uniform"):
     N = len(meshes)
     verts = meshes.verts_packed()
     faces = meshes.faces_packed()
-    weights = 1.0 / meshes.num_verts_per_mesh().gather(0, meshes.verts_packed_to_mesh_idx()).float()
+    weights = meshes.inv_num_verts_packed()
     V = verts.shape[0]
     if verts.is_cuda and method in ("cot", "uniform"):
         from .. import ops  # fused gfx950 kernels (csrc/acfm_mesh.hip); torch ops below = host tensors

@@ -11,6 +11,16 @@ from .. import _lib
 _EDGE_CACHE = {}
 
 
+def _may_keep(t):
+    """A tensor made while a hipGraph is being captured lives in the graph's private pool: it must not outlive the
+    capture in a module-level table (eager code would read memory the graph reuses)."""
+    return not (t.is_cuda and torch.cuda.is_current_stream_capturing())
+
+
+_FACES_PACKED_CACHE = {}   # same keying and lifetime rule as _EDGE_CACHE: (padded faces tensor, V) -> packed faces
+_WEIGHT_CACHE = {}         # (meshes, verts per mesh, device) -> 1 / V per packed vertex
+
+
 class Meshes:
     def __init__(self, verts=None, faces=None, textures=None):
         if torch.is_tensor(verts):
@@ -81,6 +91,21 @@ class Meshes:
             return self._verts_padded.reshape(-1, 3)
         return torch.cat(self._verts_list, 0)
 
+    def inv_num_verts_packed(self):
+        """1 / (vertices of its mesh) per packed vertex, float32 (the weights of mesh_laplacian_smoothing); a constant
+        per (batch size, mesh size) for equal-sized batches, kept."""
+        if self._equal_sized():
+            key = (len(self), self._verts_list[0].shape[0], str(self.device))
+            w = _WEIGHT_CACHE.get(key)
+            if w is None:
+                w = torch.full((key[0] * key[1],), 1.0 / max(key[1], 1), dtype=torch.float32, device=self.device)
+                if _may_keep(w):
+                    if len(_WEIGHT_CACHE) > 16:
+                        _WEIGHT_CACHE.clear()
+                    _WEIGHT_CACHE[key] = w
+            return w
+        return 1.0 / self.num_verts_per_mesh().gather(0, self.verts_packed_to_mesh_idx()).float()
+
     def mesh_to_verts_packed_first_idx(self):
         n = self.num_verts_per_mesh()
         return torch.cumsum(n, 0) - n
@@ -92,6 +117,22 @@ class Meshes:
 
     def faces_packed(self):
         if "faces_packed" not in self._cache:
+            if self._faces_padded is not None and self._equal_sized():
+                # batches of one topology build a new Meshes every step around the SAME faces tensor: the packed ids
+                # (three small launches) are memoised on it like the edges below
+                fp_ = self._faces_padded
+                ck = (fp_.data_ptr(), tuple(fp_.shape), tuple(fp_.stride()), fp_._version, str(fp_.device),
+                      str(fp_.dtype), self._verts_list[0].shape[0])
+                hit = _FACES_PACKED_CACHE.get(ck)
+                if hit is None:
+                    first = self.mesh_to_verts_packed_first_idx()
+                    hit = (fp_, (fp_.long() + first[:, None, None]).reshape(-1, 3))
+                    if _may_keep(hit[1]):
+                        if len(_FACES_PACKED_CACHE) > 16:
+                            _FACES_PACKED_CACHE.clear()
+                        _FACES_PACKED_CACHE[ck] = hit
+                self._cache["faces_packed"] = hit[1]
+                return hit[1]
             first = self.mesh_to_verts_packed_first_idx()
             if self._faces_padded is not None and self._equal_sized():
                 fp = (self._faces_padded.long() + first[:, None, None]).reshape(-1, 3)
@@ -122,7 +163,7 @@ class Meshes:
                 V = int(self.num_verts_per_mesh().sum().item())
                 h = torch.unique(e[:, 0] * V + e[:, 1], sorted=True)
                 self._cache["edges_packed"] = torch.stack([h // V, h % V], 1)
-                if ck is not None:
+                if ck is not None and _may_keep(self._cache["edges_packed"]):
                     if len(_EDGE_CACHE) > 16:
                         _EDGE_CACHE.clear()
                     _EDGE_CACHE[ck] = (fp_, self._cache["edges_packed"])
