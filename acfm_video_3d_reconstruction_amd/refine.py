@@ -18,14 +18,22 @@ def refine_total(renderer, solver, delta, cam, faces, masks, edts_barrier, bound
     cameras `cam` [N,7]: -> (total, pred_v).  refine_clip() differentiates exactly this."""
     pred_v = solver(delta)                                                    # predictor.py:310-315
     mask_pred, pix_to_face = renderer(pred_v, faces, cam)                     # :317
-    l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
     pred_proj = renderer.project_points(pred_v, cam)                          # :319
-    bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
-    # mask_loss = l1.mean() (:318), edt_loss = edt.mean() (:320); the reference pairs bdt_reg_wt with
-    # the EDT term and edt_reg_wt with the boundary term (:322); total as at :343-344, with the two
-    # per-frame means folded into one
-    per_frame = mask_loss_wt * l1 + (boundaries_reg_wt * bdt_reg_wt) * edt
-    total = per_frame.mean() + (boundaries_reg_wt * edt_reg_wt) * bdt_loss
+    # mask_loss = l1.mean() (:318), edt_loss = edt.mean() (:320), bdt_loss = per-frame boundary term .mean() (:321);
+    # the reference pairs bdt_reg_wt with the EDT term and edt_reg_wt with the boundary term (:322); total as at
+    # :343-344.  On the GPU the three weighted per-frame means are ONE launch each way (loss_utils.combine_losses on
+    # the raw [N,4] output of the silhouette-loss kernel + the per-frame boundary term) instead of ~20 elementwise /
+    # reduction launches on N-element vectors.
+    if mask_pred.is_cuda:
+        raw = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier, raw=True)   # (l1, ., ., edt) per frame
+        bdt = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face, reduce=False)   # :321
+        total = loss_utils.combine_losses([raw, bdt], [mask_loss_wt, 0.0, 0.0, boundaries_reg_wt * bdt_reg_wt,
+                                                       boundaries_reg_wt * edt_reg_wt])
+    else:
+        l1, _, edt = loss_utils.fused_silhouette_losses(mask_pred, masks, edts_barrier)
+        bdt_loss = loss_utils.bds_loss(pred_proj, boundaries, faces, pix_to_face)  # :321
+        per_frame = mask_loss_wt * l1 + (boundaries_reg_wt * bdt_reg_wt) * edt
+        total = per_frame.mean() + (boundaries_reg_wt * edt_reg_wt) * bdt_loss
     if of_loss_wt > 0 and optical_flows is not None:
         b = optical_flows.shape[0]
         masks_of = masks.reshape(b, num_frames, masks.shape[1], masks.shape[2])
