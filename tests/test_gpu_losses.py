@@ -686,6 +686,53 @@ def test_texture_cycle_term_vs_the_oracle_restatement():
 
 
 @pytest.mark.gpu
+def test_hypothesis_cameras_with_dropped_hypotheses(meshes):
+    """MultiframeStep.hypothesis_cameras on the GPU (one fused kernel from the embedding tables) == the reference's chain
+    written out with torch ops (harness.decode_cameras / mirror_cameras / transform_cameras on the stacked look-ups,
+    main.py:551-584), with all hypotheses and with only the k most probable ones of every frame (main.py:541-548,
+    568-570: drop_hypothesis), gradients to every embedding table included."""
+    from acfm_video_3d_reconstruction_amd import harness
+    from acfm_video_3d_reconstruction_amd.multiframe_step import MultiframeStep
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    B, T, G = 3, 2, 5
+    N = B * T
+    step = MultiframeStep(torch.tensor(v, device=d), torch.tensor(f, device=d), torch.tensor(fps_lbs_logits(v, 4), device=d),
+                          num_training_frames=20, img_size=32, num_guesses=G, num_lbs=4, scale_lr_decay=0.05,
+                          drop_hypothesis=True).to(d)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    with torch.no_grad():
+        for emb in step.cameras:
+            emb.weight.add_(0.3 * torch.randn(emb.weight.shape, generator=g).to(d))
+        step.prob_embeddings.weight.copy_(torch.rand(step.prob_embeddings.weight.shape, generator=g).to(d))
+    fi = torch.randperm(20, generator=g)[:N].reshape(B, T).to(d)
+    mf = torch.tensor([0, 1, 1, 0, 0, 1], device=d)
+    tr = torch.cat([torch.rand(N, 1, generator=g) + 0.5, torch.rand(N, 2, generator=g) - 0.5,
+                    (torch.rand(N, 1, generator=g) > 0.5).float()], 1).to(d)
+    w = torch.randn(G * N, 7, generator=g).to(d)
+    for k in (G, 2):
+        step.set_num_guesses(k)
+        sel = step.selected_hypotheses(fi)
+        assert (sel is None) == (k == G)
+        step.zero_grad(set_to_none=True)
+        got = step.hypothesis_cameras(fi, mf, tr, selected=sel)
+        (got * w[:k * N]).sum().backward()
+        g_fused = [e.weight.grad.clone() for e in step.cameras]
+        step.zero_grad(set_to_none=True)
+        cams = torch.stack([emb(fi) for emb in step.cameras])
+        if sel is not None:
+            cams = torch.gather(cams, 0, sel[..., None].expand(-1, -1, -1, 7))
+        want = harness.decode_cameras(cams.reshape(k, -1, 7), 0.05).reshape(-1, 7)
+        want = harness.mirror_cameras(want, None, mf.repeat(k)[:, None])
+        want = harness.transform_cameras(want, None, tr.repeat(k, 1))
+        (want * w[:k * N]).sum().backward()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        for a, e in zip(g_fused, step.cameras):
+            np.testing.assert_allclose(a.cpu().numpy(), e.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_hypothesis_total_matches_the_torch_formula():
     """harness.hypothesis_total == the reference's per-hypothesis total + softmax weighting (multiframe/main.py:716-746:
     total = sum w_t T_t, probs = softmax(-total, 0).detach(), weighted = (total * probs).sum(0).mean()), the logged sums
