@@ -21,9 +21,11 @@ class NeuralRenderer(torch.nn.Module):
     current HIP stream."""
 
     def __init__(self, img_size=256, faces_per_pixel=20, sigma=1e-4, gamma=1e-4, pix_to_face_slots=None, storage="f32"):
-        """pix_to_face_slots: None -> pix_to_face [N,H,W,faces_per_pixel] exactly like the
-        reference; 1 -> only the nearest-face plane [N,H,W,1] is written to HBM (all the
-        reference's callers read: `pix_to_face[..., 0]` loss_utils.py:214, `[..., :1]` :431).
+        """pix_to_face_slots: None -> pix_to_face [N,H,W,faces_per_pixel] int64 like the reference's, as an
+        ops.LazyPixToFace: the render writes the nearest-face plane (all the reference's callers read:
+        `pix_to_face[..., 0]` loss_utils.py:214, `[..., :1]` :431 -- both are views of it) and the other planes are
+        rendered when something first touches them; faces_per_pixel -> every slot is stored at render time
+        (160 bytes per pixel at K = 20); 1 -> only the nearest-face plane [N,H,W,1] exists.
         The mask always blends the faces_per_pixel nearest faces."""
         super().__init__()
         self.img_size = img_size
@@ -31,7 +33,7 @@ class NeuralRenderer(torch.nn.Module):
         # atlas are held in float16 and pix_to_face is the int32 nearest-face plane [N,H,W,1]; every decision of the
         # rasteriser and every loss sum stays float32 (ids identical to the float32 renderer)
         self.storage = storage
-        self.pix_to_face_slots = 1 if storage == "f16" else pix_to_face_slots
+        self.pix_to_face_slots = 1 if storage == "f16" else ("lazy" if pix_to_face_slots is None else pix_to_face_slots)
         self.faces_per_pixel = faces_per_pixel          # nmr.py:158
         self.sigma = sigma                              # nmr.py:153
         self.gamma = gamma

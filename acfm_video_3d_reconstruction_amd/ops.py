@@ -501,6 +501,84 @@ def correlation(f1, f2, max_displacement):
     return out
 
 
+# ------------------------------------------------------------------------------ lazy pix_to_face
+class LazyPixToFace(torch.Tensor):
+    """`pix_to_face [N,H,W,K]` int64 as the reference's renderer returns it, with the K-1 planes nobody in the training
+    path reads produced on first use.  The render writes the nearest-face plane (all that loss_utils.py:214 `[..., 0]`
+    and :431 `[..., :1]` read: 8 bytes per pixel instead of 8 K); `p[..., 0]` and `p[..., :1]` are views of it; ANY other
+    operation (indexing another slot, .cpu(), comparisons, printing ...) first renders the full tensor -- the same
+    kernel once more with all K slots stored, from the very tensors of the original call -- and then behaves like the
+    plain tensor.  If those inputs changed meanwhile (in-place write, or a hipGraph replay that may have rewritten
+    static buffers) it raises instead of returning ids of other geometry: NeuralRenderer(pix_to_face_slots=K) stores
+    all K slots at render time."""
+
+    @staticmethod
+    def __new__(cls, plane0, K, make_full):
+        N, H, W, _ = plane0.shape
+        r = torch.Tensor._make_wrapper_subclass(cls, (N, H, W, int(K)), dtype=plane0.dtype, device=plane0.device)
+        r._plane0, r._make_full, r._full = plane0, make_full, None
+        return r
+
+    @property
+    def is_materialized(self):
+        return self._full is not None
+
+    def materialize(self):
+        if self._full is None:
+            self._full = self._make_full()
+            self._make_full = None
+        return self._full
+
+    def __repr__(self):
+        return "LazyPixToFace(shape=%s, materialized=%s)" % (tuple(self.shape), self.is_materialized)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        a0 = args[0] if args else None
+        if isinstance(a0, LazyPixToFace) and a0._full is None:
+            nd = a0.dim()
+            if func is torch.ops.aten.select.int and args[1] in (nd - 1, -1) and args[2] == 0:
+                return a0._plane0.select(nd - 1, 0)
+            if func is torch.ops.aten.slice.Tensor and len(args) >= 4 and args[1] in (nd - 1, -1) and \
+                    args[2] in (0, None) and args[3] == 1 and (len(args) < 5 or args[4] == 1):
+                return a0._plane0
+            if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default):
+                return a0
+        from torch.utils._pytree import tree_map
+        unwrap = lambda x: x.materialize() if isinstance(x, LazyPixToFace) else x
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
+
+
+def _lazy_pix_to_face(plane0, vis, v, f, c, H, K, blur, sigma, offset_z):
+    """Wraps the nearest-face plane of a silhouette render (see LazyPixToFace)."""
+    versions = (v._version, f._version, c._version, _EPOCH[0])
+    tune = _lib.tuning()[1]
+
+    def make_full():
+        if (v._version, f._version, c._version, _EPOCH[0]) != versions:
+            raise RuntimeError("pix_to_face: slots beyond [..., 0] are rendered on first use, but the vertices / faces / "
+                               "cameras of that render have been modified since (in-place write or a hipGraph replay); "
+                               "use NeuralRenderer(pix_to_face_slots=faces_per_pixel) to store every slot at render time")
+        N, V, _ = v.shape
+        F = f.shape[1]
+        mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
+        full = torch.empty((N, H, H, K), dtype=torch.int64, device=v.device)
+        kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)
+        vis2 = torch.empty((N, V), dtype=torch.uint8, device=v.device)
+        ws, nb = _workspace(N, V, F, H, v.device)          # its own workspace: the render's is still the backward's
+        with torch.no_grad(), torch.cuda.device(v.device):
+            _lib.check(_lib.lib().acfm_sil_forward(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, K, float(blur), float(sigma), float(offset_z),
+                _lib.ptr(mask), _lib.ptr(full), _lib.ptr(kth), _lib.ptr(vis2), _lib.ptr(ws), nb,
+                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_forward")
+        return full
+
+    p = LazyPixToFace(plane0, K, make_full)
+    p._acfm_vis = vis
+    return p
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod
@@ -561,8 +639,12 @@ def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_S
     nearest face, = what bds_loss / optical_flow_loss derive from pix_to_face[..., 0]) rides
     along on the pix_to_face tensor object as `._acfm_vis`."""
     f16 = _is_f16(storage)   # "f16": mask [N,H,H] float16, pix_to_face [N,H,H,1] int32 (BASELINE config 5); fp32 arithmetic
+    lazy = k_out == "lazy" and not f16 and K > 1
     mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z,
-                                      (1 if f16 else K) if k_out is None else int(k_out), f16)
+                                      1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)), f16)
+    if lazy:   # k_out="lazy": [N,H,H,K] whose slots 1.. are rendered on first use (LazyPixToFace)
+        return mask, _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
+                                       int(img_size), int(K), blur, sigma, offset_z)
     p2f._acfm_vis = vis
     return mask, p2f
 
@@ -639,8 +721,13 @@ def sil_render_losses(verts, faces, cams, img_size, gt=None, edt=None, K=SIL_K, 
     carries none (use sil_render when the mask itself feeds further differentiable code).  gt / edt: [N,...] or
     [N/G,...] shared by the G hypotheses of a frame."""
     f16 = _is_f16(storage)   # "f16": mask and the references are held in float16, the loss sums stay float32
+    lazy = k_out == "lazy" and not f16 and K > 1
     losses, mask, p2f, vis = _SilRenderLosses.apply(verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z,
-                                                    (1 if f16 else K) if k_out is None else int(k_out), f16)
+                                                    1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)),
+                                                    f16)
+    if lazy:
+        return losses, mask, _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
+                                               int(img_size), int(K), blur, sigma, offset_z)
     p2f._acfm_vis = vis
     return losses, mask, p2f
 
@@ -1076,6 +1163,8 @@ def visible_vertices(pix_to_face, faces, nv):
     fused = getattr(pix_to_face, "_acfm_vis", None)
     if fused is not None and fused.shape == (pix_to_face.shape[0], nv):
         return fused
+    if isinstance(pix_to_face, LazyPixToFace) and not pix_to_face.is_materialized:
+        pix_to_face = pix_to_face[..., :1]          # the stand-alone kernel reads slot 0 only
     _lib.require_gpu(pix_to_face, faces)
     p = pix_to_face.detach().to(torch.int64).contiguous()
     N, K = p.shape[0], p.shape[-1]

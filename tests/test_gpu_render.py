@@ -300,6 +300,55 @@ def test_silhouette_nearest_plane_only(meshes):
         assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
 
 
+def test_lazy_pix_to_face(meshes):
+    """The default NeuralRenderer returns pix_to_face [N,H,W,K] as an ops.LazyPixToFace: `[..., 0]` / `[..., :1]` (what
+    the reference's callers read) and bds_loss never produce the other planes; anything else does, and then the tensor
+    equals the one rendered with every slot stored (and the oracle's); stale inputs make it raise."""
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _dev()
+    n, H = 3, 64
+    verts, f, cams = _setup(meshes, "bird", n, 71)
+    faces = torch.from_numpy(f)[None].repeat(n, 1, 1).to(d)
+    tv = torch.tensor(verts, device=d, requires_grad=True)
+    tc = torch.tensor(cams, device=d, requires_grad=True)
+    ren = NeuralRenderer(H)
+    m, p = ren(tv, faces, tc)
+    m_e, p_e = NeuralRenderer(H, pix_to_face_slots=20)(tv, faces, tc)
+    assert isinstance(p, ops.LazyPixToFace) and not isinstance(p_e, ops.LazyPixToFace)
+    assert p.shape == p_e.shape == (n, H, H, 20) and p.dtype == torch.int64 and p.device == p_e.device
+    assert torch.equal(p[..., 0], p_e[..., 0]) and torch.equal(p[..., :1], p_e[..., :1]) and not p.is_materialized
+    bds = torch.cat([torch.rand(n, 40, 2, device=d) * 2 - 1, torch.ones(n, 40, 1, device=d)], -1)
+    la = L.bds_loss(ren.project_points(tv, tc), bds, faces, p, reduce=False)
+    lb = L.bds_loss(ren.project_points(tv, tc), bds, faces, p_e, reduce=False)
+    assert torch.equal(la, lb) and not p.is_materialized
+    assert torch.equal(ops.visible_vertices(p, faces, verts.shape[1]), ops.visible_vertices(p_e, faces, verts.shape[1]))
+    assert torch.equal(m, m_e)
+    # anything else renders the other planes, once
+    assert torch.equal(p[..., 5], p_e[..., 5]) and p.is_materialized
+    assert torch.equal(p, p_e) and int((p >= 0).sum()) == int((p_e >= 0).sum())
+    _, ref = O.sil_render(verts, f, cams, H)
+    np.testing.assert_array_equal(p.cpu().numpy(), ref)
+    # gradients are those of the eager render
+    g = torch.randn(n, H, H, device=d)
+    for x, y in zip(torch.autograd.grad((m * g).sum(), [tv, tc]), torch.autograd.grad((m_e * g).sum(), [tv, tc])):
+        assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
+    # stale inputs: loud
+    _, p2 = ren(tv, faces, tc)
+    with torch.no_grad():
+        tv.add_(0.0)
+    assert torch.equal(p2[..., 0], p_e[..., 0])
+    with pytest.raises(RuntimeError):
+        p2.cpu()
+    # the fused operator hands out the same kind of tensor
+    gt = (torch.rand(n, H, H, device=d) > 0.5).float()
+    edt = torch.rand(n, 1, H, H, device=d)
+    _, _, p3 = ren.forward_silhouette_losses(tv, faces, tc, gt, edt, raw=True)
+    assert isinstance(p3, ops.LazyPixToFace) and torch.equal(p3[..., 0], p_e[..., 0])
+    assert torch.equal(p3[..., 19], p_e[..., 19])
+
+
 def test_vertex_color_render_atlas_false(meshes):
     from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
     d = _dev()
