@@ -450,7 +450,7 @@ def main():
         alg = {
             # read verts 12V + cam 28 (+ faces 12F shared, once per batch); write mask 4H^2 + nearest face id 8H^2
             "k_raster_fwd<K,soft>": N * (12 * H * H + 12 * V + 28) + 12 * F,
-            # read grad 4H^2 + mask 4H^2 + nearest id 8H^2; write grad_verts 12V + grad_cam 28
+            # read grad 4H^2 + mask 4H^2 + K-th key 8H^2; write grad_verts 12V + grad_cam 28
             "k_sil_bwd": N * (16 * H * H + 12 * V + 28),
             # read atlas 12FR^2 ; write image 12H^2 + sil 4H^2 + face id 8H^2
             "k_raster_fwd<1,tex>": N * (24 * H * H + 12 * F * R * R + 12 * V + 28),
@@ -507,7 +507,11 @@ def main():
             if pmk.get("thread_cycles_valu") and pmk.get("active_inst_valu"):
                 v["lanes_active"] = round(pmk["thread_cycles_valu"] / (64 * pmk["active_inst_valu"]), 4)
             roof["valu"] = v
-            roof["limiter"] = "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)"
+            v["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): an estimate, a few % above 1 when saturated"
+            roof["limiter"] = {
+                "k_sil_bwd": "VALU issue (per pixel x face pair: membership test key <= kth, exact edge distance again, its "
+                             "backward to three vertices, 4 DPP row shifts per gradient component before the LDS accumulators)",
+            }.get(dom, "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)")
         if traffic:   # what the kernel actually moves (the API's K int64 ids per pixel dominate): context, not `achieved`
             moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
