@@ -59,7 +59,8 @@ def parse():
                         "deformation system and the ranks exchange the pre-solve sums [G = sum g delta^T | sum g | loss] "
                         "(~50 KB, sharding.SharedShapeExchange) instead of the mean-shape gradient alone; eager launches")
     p.add_argument("--tex-stream", type=int, default=0,
-                   help="texture branch on its own HIP stream (measured slower: 1.34 vs 1.26 ms/step)")
+                   help="texture branch forked onto its own HIP stream behind the silhouette forward (graph edges in a capture); "
+                        "measured: no gain, 0.693 vs 0.689 ms/step -- every kernel of either branch fills the chip")
     return p.parse_args()
 
 
@@ -165,19 +166,21 @@ def main():
                 flat_views[0].copy_(g_mean)
                 flat_extra.copy_(total.detach().reshape(1))
             return total.detach(), g_delta, g_cams, g_mean, g_atlas
-        tex_term = None
-        if side is not None:
-            # experiment (off by default): the texture branch reads detached geometry only
-            # (main.py:627-636), so it can run on its own HIP stream beside the silhouette kernels
-            cur = torch.cuda.current_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
-                tex_term = 0.5 * L.masked_texture_mse(tex, imgs_gt, gt_mask).mean()  # main.py:655-662
         if fused:   # opt-in operator: the loss terms leave the raster kernel with the mask (acfm_sil_loss_*)
             sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_mask, edt, raw=True)
         else:
             mask, p2f = ren(pred_v, faces, cams)                             # a3
+        tmse = None
+        if side is not None:
+            # the texture branch reads detached geometry only (main.py:627-636): forked onto its own HIP stream behind
+            # the silhouette forward (whose face setup it takes over), it runs -- forward here, backward wherever autograd
+            # reaches it -- beside the loss kernels and the silhouette backward; in a capture these are graph edges
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
+                tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)               # main.py:655-662
+        if not fused:
             sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)   # a10, a11: [N,4] = (l1, ., ., edt)
         proj = ren.project_points(pred_v, cams)                          # a2
         bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
@@ -185,7 +188,7 @@ def main():
         # (combine_losses) instead of ~13 elementwise launches on 64-element vectors
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-            total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1]) + tex_term
+            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
         elif a.tex:
             if fused:
                 tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_gt, gt_mask)[0]
@@ -250,7 +253,7 @@ def main():
     graph_note = []
 
     def timed(ren, warmup, steps, use_graph=None, fused=False):
-        use_graph = (not a.eager and side is None) if use_graph is None else use_graph
+        use_graph = (not a.eager) if use_graph is None else use_graph
         fn = (lambda r: step(r, True)) if fused else step
         if use_graph:
             try:
@@ -316,7 +319,7 @@ def main():
     dt = timed(renderer, a.warmup, a.steps)          # the drop-in API: pix_to_face [N,H,W,20] int64
     ms_step = 1e3 * dt / a.steps
     value = world * N * a.steps / dt
-    use_graph = not a.eager and side is None
+    use_graph = not a.eager
     # the other launch mode of the same step, reported beside the headline (never instead of it)
     extras = not cfg5 and not a.headline_only
     dt_other = timed(renderer, max(2, a.warmup // 2), a.steps, use_graph=not use_graph) if side is None and extras else None
