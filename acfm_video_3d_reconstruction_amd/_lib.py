@@ -164,11 +164,15 @@ class raster_tuning:
     Tests use it to force the split / unsplit kernels and every grid divisor; the library itself keeps
     no tuning state."""
 
-    def __init__(self, split=-3, grid_div=(0, 0, 0), deterministic=False):
+    def __init__(self, split=-3, grid_div=(0, 0, 0), deterministic=False, record_cover=None):
         """deterministic=True: the silhouette backward accumulates in fixed point (bit-reproducible run to run).
+        record_cover: True / False forces ACFM_RECORD_COVER (the silhouette render leaves the nearest covering face
+        per pixel for a texture render that takes its workspace over) on / off; None lets ops.py decide -- on while
+        texture renders do follow the silhouette renders on this device.
         (Bit 1 of the flags, half storage, is not set here: it changes buffer types, so the ops that support it take
         storage="f16" and set it themselves -- with_f16() below.)"""
         self.t = RasterTuning(int(split), (_i * 3)(*[int(d) for d in grid_div]), 1 if deterministic else 0)
+        self.t.record_cover = record_cover   # (a Python attribute: not part of the C structure)
 
     def __enter__(self):
         self.prev = getattr(_TUNE, "cur", None)
@@ -194,6 +198,15 @@ def with_f16(t, on):
     if t is None:
         return RasterTuning(-3, (_i * 3)(0, 0, 0), 2) if on else None
     return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~2) | (2 if on else 0))
+
+
+def with_cover(t, on):
+    """The tuning in effect with flags bit 2 (ACFM_RECORD_COVER) set or cleared: a fresh structure (None = defaults)."""
+    if t is None:
+        return RasterTuning(-3, (_i * 3)(0, 0, 0), 4) if on else None
+    if bool(t.flags & 4) == bool(on):
+        return t
+    return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~4) | (4 if on else 0))
 
 
 _CONSTS = {}

@@ -82,6 +82,9 @@ struct RasterWs {
   float4* lpart;   // [N,blocks^2,4] fused render+loss: per 8x8 block (x 4 split roles) partial sums of the silhouette
                    // loss terms, written by the raster kernel, summed in fixed order by k_sil_loss_finish
   float* lpart2;   // [N,64,5] second-stage partial sums of the same
+  int* cover;      // [N,H,H] nearest face that COVERS the pixel (the hard K = 1 render's answer: clipped-barycentric depth,
+                   // pixel strictly inside), local face id or -1; written by the K-nearest forward on request (Tune::cover)
+                   // for the blocks that have work, read by the texture forward that takes the workspace over
   size_t bytes;
 };
 
@@ -95,6 +98,7 @@ struct Tune {
                              // (measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us)
   bool deterministic = false; // flags bit 0: fixed-point accumulation in the silhouette backward
   bool f16 = false;           // flags bit 1: half storage of masks / images / atlases, int32 nearest-face plane
+  bool cover = false;         // flags bit 2: the K-nearest forward also records the nearest COVERING face per pixel (ws.cover)
 };
 static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
   if (!t) return true;
@@ -104,9 +108,10 @@ static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
     if (t->grid_div[i] < 0 || t->grid_div[i] > 64) return false;
     if (t->grid_div[i] > 0) out.div[i] = t->grid_div[i];   // 0 = keep the default
   }
-  if (t->flags & ~3) return false;
+  if (t->flags & ~7) return false;
   out.deterministic = (t->flags & 1) != 0;
   out.f16 = (t->flags & 2) != 0;
+  out.cover = (t->flags & 4) != 0;
   return true;
 }
 
@@ -139,6 +144,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
   w.cmask = (unsigned*)(p + o); o += align256(sizeof(unsigned) * 2 * (size_t)N * ct * words);
   w.lpart = (float4*)(p + o);   o += align256(sizeof(float4) * 4 * (size_t)N * tt);
   w.lpart2 = (float*)(p + o);   o += align256(sizeof(float) * 5 * 64 * (size_t)N);
+  w.cover = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * H * H);
   w.bytes = o;
   return w;
 }

@@ -807,6 +807,21 @@ struct Hit { float pz, sd, c0, c1, c2, d01, d02, d12; };
 //   stage 2: the three edge distances;  rejects !inside && d >= blur
 // INSIDE_ONLY: the caller keeps only pixels inside the face (blur == 0): the others leave before
 // the clipped barycentrics and the depth are computed.
+// clip_barycentric_coords (the texture branch): clamp to [0,1], renormalise by max(sum, 1e-5); and the depth
+// interpolated with whichever barycentrics apply.  One definition each: the K-nearest forward evaluates the
+// clipped depth of a covering face too (ACFM_RECORD_COVER) and must land on the bits of the K = 1 render.
+__device__ __forceinline__ void clip_bary(float& c0, float& c1, float& c2) {
+  c0 = fmaxf(fminf(c0, 1.0f), 0.0f);
+  c1 = fmaxf(fminf(c1, 1.0f), 0.0f);
+  c2 = fmaxf(fminf(c2, 1.0f), 0.0f);
+  const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+  const float rs = recip_refined(s);
+  c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
+}
+__device__ __forceinline__ float bary_depth(float c0, float c1, float c2, float z0, float z1, float z2) {
+  return c0 * z0 + c1 * z1 + c2 * z2;
+}
+
 template <bool CLIP, bool INSIDE_ONLY = false>
 __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4& A, const float4& B,
                                                 float z2, float area, Hit& h, bool& inside) {
@@ -822,15 +837,8 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
   float c0 = w0, c1 = w1, c2 = w2;
   inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
   if (INSIDE_ONLY && !inside) return false;
-  if (CLIP) {
-    c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
-    c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
-    c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
-    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-    const float rs = recip_refined(s);
-    c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
-  }
-  const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+  if (CLIP) clip_bary(c0, c1, c2);
+  const float pz = bary_depth(c0, c1, c2, z0, z1, z2);
   h.pz = pz; h.c0 = c0; h.c1 = c1; h.c2 = c2;
   return !(pz < 0.0f);
 }
@@ -951,6 +959,10 @@ struct FwdOut {
   // (tex m - img m)^2 - (img m)^2 over its covered pixels (elsewhere tex = 0 and the difference vanishes)
   const void* timg;          // [lrb,3,H,H] real_t reference images
   const void* tmask;         // [lrb,H,H] real_t reference masks
+  // ACFM_RECORD_COVER: the K-nearest forward writes ws.cover (cover_out), the texture forward that takes the
+  // workspace over reads it (cover_in) instead of walking the faces
+  int* cover_out;
+  const int* cover_in;
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -1456,6 +1468,21 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       pix_lists_walk<false, false>(ws, t, F, H, blur, out.box_shrink, P,
                                    [&](bool have, int c) { body1(have, c, std::false_type()); });
 #else
+    if (TEX && out.cover_in) {
+      // the K-nearest render of this geometry recorded the nearest covering face of every pixel (same inside test,
+      // same clipped depth, same tie-break): evaluate that one face again for its barycentrics
+      if (t.valid) {
+        const int f = out.cover_in[t.pix];
+        if (f >= 0) {
+          const FaceRec& r = ws.rec[(size_t)n * F + f];
+          const float4 ra = r.a, rb = r.b, rc = r.c;
+          Hit h;
+          bool inside = false;
+          test_face_depth<CLIP, true>(t.xf, t.yf, ra, rb, rc.x, rc.y, h, inside);
+          bestkey = make_key(h.pz, f); bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2;
+        }
+      }
+    } else
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
@@ -1560,6 +1587,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 #pragma unroll
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
+    unsigned long long cbest = KEY_NONE;   // ACFM_RECORD_COVER: nearest covering face so far
 #if ACFM_FWD_V2
     auto& P = S.p;
     pix_lists_walk<false, true>(ws, t, F, H, blur, out.box_shrink, P, [&](bool have, int c) {
@@ -1600,6 +1628,19 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         bool inside = false;
         bool live = in_box && t.valid &&
                     test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside);
+        if (out.cover_out) {
+          // the hard K = 1 render's candidate test for this pair (test_face_depth<true, true>): strictly inside,
+          // depth from the CLIPPED barycentrics (h.c* hold the unclipped ones here), not negative.  Before the
+          // K-th-key filter below: the nearest covering face need not be among the K nearest kept faces.
+          const bool cin = in_box && t.valid && inside;
+          if (__ballot(cin) != 0ull) {
+            float c0 = h.c0, c1 = h.c1, c2 = h.c2;
+            clip_bary(c0, c1, c2);
+            const float pzc = bary_depth(c0, c1, c2, cd.b.z, cd.b.w, cd.c.x);
+            const unsigned long long xc = make_key(pzc, cd.fid);
+            if (cin && !(pzc < 0.0f) && xc < cbest) cbest = xc;
+          }
+        }
         unsigned long long x = make_key(h.pz, cd.fid);
         live = live && (x < key[K - 1]);
         if (__ballot(live) == 0ull) return;
@@ -1643,6 +1684,18 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       }
     }
     const bool out_valid = t.valid && (!split || t.lane < 16);
+    if (out.cover_out) {
+      if (split) {   // the four 16-lane groups saw different candidates of the same 16 pixels
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(cbest & 0xffffffffull), m, 64);
+          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(cbest >> 32), m, 64);
+          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+          if (o < cbest) cbest = o;
+        }
+      }
+      if (out_valid) out.cover_out[t.pix] = cbest != KEY_NONE ? (int)(cbest & 0xffffffffu) : -1;
+    }
     float lmask = 0.f, lg = 0.f, le = 0.f;
     if (out.lpart && out_valid) {
       const size_t rp = t.pix - (size_t)n * H * H + (size_t)(n % out.lrb) * H * H;
@@ -2621,6 +2674,7 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.V = V;
   out.sig_scale = 1.44269504088896341f / sigma;
   out.lrb = 1;
+  if (tn.cover) out.cover_out = ws.cover;
   if (fused) { out.lgt = gt; out.ledt = edt; out.lrb = ref_batch; out.lpart = ws.lpart; }
   switch (K) {
     case 20: rc = launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
@@ -2780,6 +2834,10 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.h16 = tn.f16 ? 1 : 0;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   out.lrb = 1;
+  if (ws_ready == 2) {
+    if (!tn.cover) return ACFM_E_BADARG;   // the tuning of the render that filled the workspace says whether the plane is there
+    out.cover_in = ws.cover;
+  }
   if (loss) {
     if (!ref_img || !ref_mask || ref_batch <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;
     out.timg = ref_img; out.tmask = ref_mask; out.lrb = ref_batch; out.lpart = ws.lpart;

@@ -124,6 +124,33 @@ def _setup_key(v, c, f, H, offset_z):
             _capture_id(v.device), _EPOCH[0])
 
 
+# ACFM_RECORD_COVER: the silhouette render can note the nearest COVERING face of every pixel on its way (a few
+# instructions per covering pair), and the texture render that takes its workspace over then shades from that plane
+# instead of binning and walking the faces again (70 -> ~30 us per 64 frames @256^2).  Worth it only when a texture
+# render does follow, which the renderer cannot know: per device, the flag is on while the previous silhouette
+# render's plane was used, and goes off when a plane was left unread.  Pure speed: outputs are bit-identical.
+_COVER = {}
+
+
+def _cover_tuning(device, tune):
+    """Tuning for a silhouette render on `device`: `tune` with the cover flag decided."""
+    forced = getattr(tune, "record_cover", None) if tune is not None else None
+    st = _COVER.setdefault(device, {"on": False, "pending": False})
+    if forced is not None:
+        return _lib.with_cover(tune, bool(forced))
+    if st["pending"]:          # the last plane was never read: stop recording
+        st["on"] = False
+    st["pending"] = st["on"]
+    return _lib.with_cover(tune, st["on"])
+
+
+def _cover_taken(device, tune):
+    """A texture render took a silhouette render's workspace over: -> the ws_ready value for the C ABI."""
+    st = _COVER.setdefault(device, {"on": False, "pending": False})
+    st["on"], st["pending"] = True, False
+    return 2 if (tune is not None and tune.flags & 4) else 1
+
+
 def _shared_setup(v, c, f, H, offset_z):
     """-> (ws, nbytes, blur, tuning) of a silhouette render of exactly these inputs, or None."""
     ent = _SETUP.get(v.device) if _SHARE[0] else None
@@ -595,7 +622,9 @@ class _SilRender(torch.autograd.Function):
         kth = torch.empty((N, H, H), dtype=torch.int64, device=v.device)  # u64 keys, opaque
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
-        tune = _lib.with_f16(_lib.tuning()[1], True) if f16 else _lib.tuning()[1]
+        tune = _cover_tuning(v.device, _lib.tuning()[1])
+        if f16:
+            tune = _lib.with_f16(tune, True)
         tp = _lib.tuning_ptr(tune)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_forward(
@@ -675,7 +704,9 @@ class _SilRenderLosses(torch.autograd.Function):
         vis = torch.empty((N, V), dtype=torch.uint8, device=v.device)
         losses = torch.empty((N, 4), dtype=torch.float32, device=v.device)
         ws, nb = _workspace(N, V, F, H, v.device)
-        tune = _lib.with_f16(_lib.tuning()[1], True) if f16 else _lib.tuning()[1]
+        tune = _cover_tuning(v.device, _lib.tuning()[1])
+        if f16:
+            tune = _lib.with_f16(tune, True)
         tp = _lib.tuning_ptr(tune)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_loss_forward(
@@ -781,12 +812,13 @@ class _TexRender(torch.autograd.Function):
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
+        ws_ready = _cover_taken(v.device, tune) if shared is not None else 0
         tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), N, V, F, H, R, float(sigma),
                 float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
-                _lib.ptr(tidx), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
+                _lib.ptr(tidx), _lib.ptr(ws), nb, ws_ready, float(ws_blur), NA,
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_forward")
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R, NA, V)
@@ -862,12 +894,13 @@ class _TexRenderMSE(torch.autograd.Function):
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
+        ws_ready = _cover_taken(v.device, tune) if shared is not None else 0
         tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_mse_forward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(a), _lib.ptr(ri), _lib.ptr(rm), RB, N, V, F, H, R,
                 float(sigma), float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
-                _lib.ptr(tidx), _lib.ptr(loss), _lib.ptr(ws), nb, int(shared is not None), float(ws_blur), NA,
+                _lib.ptr(tidx), _lib.ptr(loss), _lib.ptr(ws), nb, ws_ready, float(ws_blur), NA,
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_mse_forward")
         ctx.save_for_backward(tidx, imgs, ri, rm)
         ctx.cfg = (N, F, H, R, NA, V, RB)

@@ -42,6 +42,7 @@ extern "C" {
 #define ACFM_MAX_FACES 65535 /* faces per mesh (16-bit local ids in the per-pixel lists) */
 #define ACFM_DETERMINISTIC 1 /* AcfmRasterTuning.flags */
 #define ACFM_STORE_F16 2
+#define ACFM_RECORD_COVER 4
 
 /* library / device info ------------------------------------------------------------- */
 int acfm_version(void);              /* 1000*major + minor */
@@ -224,6 +225,11 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
  *               fp32 build and losses differ by the half rounding of what is stored (IoU drift < 1e-4).
  *               Gradients (grad_mask, grad_losses, grad_atlas, grad_verts, grad_cams) are always float.
  *               These two bits are the only fields that are not pure speed.
+ *               bit 2 = ACFM_RECORD_COVER (pure speed): acfm_sil_forward / acfm_sil_loss_forward also leave, in the
+ *               workspace, the nearest face that COVERS each pixel -- the answer of the hard K = 1 render of the same
+ *               geometry (nmr.py:173-200: blur 0, clipped barycentrics), found during the walk the K-nearest render
+ *               does anyway.  A texture render that takes the workspace over with ws_ready = 2 shades from that plane
+ *               instead of binning and walking the faces again: identical outputs, bit for bit.
  * A backward call must pass the tuning of the forward whose workspace it takes over. */
 typedef struct AcfmRasterTuning {
   int split_mode;
@@ -302,6 +308,8 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
  * offset_z, left there by acfm_sil_forward with blur_radius = ws_blur (the reference renders the
  * silhouette and the texture of one prediction back to back, main.py:616-636): projection and
  * face setup are skipped and the blur-expanded boxes tightened by sqrt(ws_blur).
+ * ws_ready == 2: that acfm_sil_forward ran with ACFM_RECORD_COVER (and the same tuning is passed here): the nearest
+ * covering face of every pixel is read from the workspace, nothing is binned or walked.
  * atlas_batch: number of distinct atlases, atlas [atlas_batch,F,R,R,3]; mesh n samples atlas
  * n % atlas_batch (the trainer renders G camera hypotheses of every frame with the frame's one
  * texture, textures.repeat(G, ...) at main.py:627-636: atlas_batch = N / G spares the copies, and

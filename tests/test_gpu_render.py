@@ -214,6 +214,80 @@ def test_texture_render_takes_over_the_silhouette_setup(meshes):
         np.testing.assert_array_equal(moved[2].cpu().numpy(), ref2[2])
 
 
+def test_texture_render_from_the_cover_plane(meshes):
+    """ACFM_RECORD_COVER: the silhouette render notes the nearest COVERING face of every pixel and the texture render
+    that takes its workspace over shades from that plane instead of walking the faces (acfm_tex_forward, ws_ready = 2).
+    Bit-identical to the stand-alone texture render and to the oracle -- images, silhouettes, face ids, the atlas
+    gradient, the fused render + MSE -- with split and unsplit blocks, odd image sizes, batch sizes off the XCD
+    grouping, coincident faces (depth ties broken by face id) and K so small that the covering face is not among the
+    kept ones.  The flag switches itself on once texture renders are seen to follow silhouette renders."""
+    from acfm_video_3d_reconstruction_amd import ops, _lib
+    d = _dev()
+    cases = (("bird", 3, 128, 20, -3), ("cow", 2, 100, 20, 1), ("horse", 8, 64, 20, 0), ("bird", 5, 72, 2, -3),
+             ("bird+dup", 2, 96, 4, -3))
+    for name, n, H, K, split in cases:
+        verts, f, cams = _setup(meshes, name.split("+")[0], n, 91)
+        if name.endswith("+dup"):       # every face twice, the copies under other ids: exact depth ties at every covered pixel
+            f = np.concatenate([f, f[::-1]], 0)
+        rng = np.random.default_rng(92)
+        atlas = torch.tensor(rng.uniform(0, 1, (n, f.shape[0], 3, 3, 3)).astype(np.float32), device=d, requires_grad=True)
+        tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+        faces = torch.from_numpy(f)[None].to(d).expand(n, -1, -1)
+        gimg = torch.tensor(rng.standard_normal((n, 3, H, H)).astype(np.float32), device=d)
+        ops._SETUP.clear()
+        alone = ops.tex_render(tv, faces, tc, atlas, H)
+        g_alone, = torch.autograd.grad((alone[0] * gimg).sum(), atlas)
+        outs = {}
+        for on in (False, True):
+            with _lib.raster_tuning(split=split, record_cover=on):
+                m, p = ops.sil_render(tv, faces, tc, H, K=K)
+                hit = ops._shared_setup(tv, tc, ops.expand_faces(faces, n), H, 0.0)
+                assert hit is not None and bool(hit[3].flags & 4) == on
+                t = ops.tex_render(tv, faces, tc, atlas, H)
+                g, = torch.autograd.grad((t[0] * gimg).sum(), atlas)
+            outs[on] = (m, p[..., 0].clone(), t, g)
+        assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])   # the silhouette itself
+        for on in (False, True):
+            for a, b in zip(alone, outs[on][2]):
+                assert torch.equal(a, b), (name, on)
+            assert torch.equal(g_alone, outs[on][3]), (name, on)
+        ref = O.tex_render(verts, f, cams, atlas.detach().cpu().numpy(), H)
+        np.testing.assert_array_equal(outs[True][2][2].cpu().numpy(), ref[2])
+        np.testing.assert_allclose(outs[True][2][0].detach().cpu().numpy(), ref[0], rtol=0, atol=1e-6)
+        assert (outs[True][2][2] >= 0).any()
+    # the fused render + MSE takes the plane too
+    verts, f, cams = _setup(meshes, "bird", 4, 93)
+    rng = np.random.default_rng(94)
+    H = 96
+    atlas = torch.tensor(rng.uniform(0, 1, (4, f.shape[0], 4, 4, 3)).astype(np.float32), device=d)
+    img = torch.tensor(rng.uniform(0, 1, (4, 3, H, H)).astype(np.float32), device=d)
+    gt = torch.tensor((rng.uniform(0, 1, (4, H, H)) > 0.4).astype(np.float32), device=d)
+    tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+    faces = torch.from_numpy(f)[None].to(d).expand(4, -1, -1)
+    res = []
+    for on in (False, True):
+        with _lib.raster_tuning(record_cover=on):
+            ops.sil_render(tv, faces, tc, H)
+            res.append(ops.tex_render_mse(tv, faces, tc, atlas, img, gt, H))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    # the policy: off until a texture render has followed a silhouette render, off again once a plane goes unread
+    ops._COVER.clear()
+    ops._SETUP.clear()
+    flag = lambda: bool(ops._shared_setup(tv, tc, ops.expand_faces(faces, 4), H, 0.0)[3] is not None and
+                        ops._shared_setup(tv, tc, ops.expand_faces(faces, 4), H, 0.0)[3].flags & 4)
+    ops.sil_render(tv, faces, tc, H)
+    assert not flag()
+    ops.tex_render(tv, faces, tc, atlas, H)
+    ops.sil_render(tv, faces, tc, H)
+    assert flag()
+    ops.tex_render(tv, faces, tc, atlas, H)
+    ops.sil_render(tv, faces, tc, H)
+    assert flag()
+    ops.sil_render(tv, faces, tc, H)          # the plane above was never read
+    assert not flag()
+
+
 def test_texture_atlas_shared_by_hypotheses(meshes):
     """atlas [N/G,...] for G*N/G meshes == atlas.repeat(G,...): same images, gradient = sum over the
     G copies (acfm_tex_forward / _backward, atlas_batch)."""
