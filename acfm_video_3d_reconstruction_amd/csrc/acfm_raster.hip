@@ -1423,83 +1423,15 @@ __device__ __forceinline__ void fwd_fill_block_whole(const FwdOut& out, int n, i
   }
 }
 
-template <int K, bool CLIP, bool TEX>
-__device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
-                                          const FwdOut& out, FwdLdsK<K>& S) {
-#if !ACFM_FWD_V2
-  auto& L = S.s.L;
-  fl_t* s_fl = S.s.fl;
-#endif
+// What the nearest-face (K = 1) forward does with a pixel's winner: face id, visibility, and for the texture branch
+// the atlas lookup, blend and optional fused MSE partial.  Shared by the walking kernel (fwd_block) and by the
+// kernel that reads the winner from the cover plane (k_tex_cover).
+template <bool CLIP, bool TEX>
+__device__ __forceinline__ void k1_finish(const RasterWs& ws, const Tile& t, int F, int H, float sigma, const FwdOut& out,
+                                          unsigned long long bestkey, float bestsd, float bestb0, float bestb1,
+                                          float bestb2, bool dist_late) {
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
-
-  if constexpr (K == 1) {
-    unsigned long long bestkey = KEY_NONE;
-    float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
-    // blur == 0 (every hard render of the reference): a face is accepted iff the pixel is inside it,
-    // so the three edge distances decide nothing; only the winner's signed distance is ever used
-    // (the blend weight of the texture branch) and is evaluated once per pixel after the walk.
-    const bool dist_late = !(blur > 0.0f);
-#if ACFM_FWD_V2
-    auto& P = S.p;
-    auto body1 = [&](bool have, int c, auto late) {
-      if (!have) return;
-      const float4* R = P.rec[c];
-      const float4 box = P.box[c], a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
-      // (the oracle's box test; with blur = 0 it is implied by `inside` up to rounding, and kept for that reason)
-      if ((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z)) return;
-      const PixD d = pix_deltas(t.xf, t.yf, a, b);
-      Hit h;
-      h.sd = 0.f;
-      bool inside = false;
-      if (decltype(late)::value) {
-        if (!rec_depth<CLIP, true>(d, b, cc, e01, e12, e02, h, inside)) return;
-      } else {
-        if (!rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside)) return;
-        if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
-      }
-      const unsigned long long key = make_key(h.pz, __float_as_int(cc.y));
-      if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
-    };
-    if (dist_late)
-      pix_lists_walk<true, false>(ws, t, F, H, blur, out.box_shrink, P,
-                                  [&](bool have, int c) { body1(have, c, std::true_type()); });
-    else
-      pix_lists_walk<false, false>(ws, t, F, H, blur, out.box_shrink, P,
-                                   [&](bool have, int c) { body1(have, c, std::false_type()); });
-#else
-    if (TEX && out.cover_in) {
-      // the K-nearest render of this geometry recorded the nearest covering face of every pixel (same inside test,
-      // same clipped depth, same tie-break): evaluate that one face again for its barycentrics
-      if (t.valid) {
-        const int f = out.cover_in[t.pix];
-        if (f >= 0) {
-          const FaceRec& r = ws.rec[(size_t)n * F + f];
-          const float4 ra = r.a, rb = r.b, rc = r.c;
-          Hit h;
-          bool inside = false;
-          test_face_depth<CLIP, true>(t.xf, t.yf, ra, rb, rc.x, rc.y, h, inside);
-          bestkey = make_key(h.pz, f); bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2;
-        }
-      }
-    } else
-    bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
-      walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
-        if (!(in_box && t.valid)) return;
-        Hit h;
-        h.sd = 0.f;
-        bool inside = false;
-        if (dist_late) {
-          if (!test_face_depth<CLIP, true>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
-        } else {
-          if (!test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
-          if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
-        }
-        const unsigned long long key = make_key(h.pz, cd.fid);
-        if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
-      });
-    });
-#endif
     float tacc = 0.f;     // fused texture MSE: this pixel's (tex m - img m)^2 - (img m)^2 over the three channels
     if (t.valid) {
     const bool hit = (bestkey != KEY_NONE);
@@ -1576,6 +1508,71 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         out.lpart[(((size_t)n * tiles + t.yi / RBLK) * tiles + t.xi / RBLK) * 4] = make_float4(tacc, 0.f, 0.f, 0.f);
       }
     }
+}
+
+template <int K, bool CLIP, bool TEX>
+__device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
+                                          const FwdOut& out, FwdLdsK<K>& S) {
+#if !ACFM_FWD_V2
+  auto& L = S.s.L;
+  fl_t* s_fl = S.s.fl;
+#endif
+  const int n = t.n;
+  const int64_t fbase = (int64_t)n * F;
+
+  if constexpr (K == 1) {
+    unsigned long long bestkey = KEY_NONE;
+    float bestsd = 0.f, bestb0 = 0.f, bestb1 = 0.f, bestb2 = 0.f;
+    // blur == 0 (every hard render of the reference): a face is accepted iff the pixel is inside it,
+    // so the three edge distances decide nothing; only the winner's signed distance is ever used
+    // (the blend weight of the texture branch) and is evaluated once per pixel after the walk.
+    const bool dist_late = !(blur > 0.0f);
+#if ACFM_FWD_V2
+    auto& P = S.p;
+    auto body1 = [&](bool have, int c, auto late) {
+      if (!have) return;
+      const float4* R = P.rec[c];
+      const float4 box = P.box[c], a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
+      // (the oracle's box test; with blur = 0 it is implied by `inside` up to rounding, and kept for that reason)
+      if ((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z)) return;
+      const PixD d = pix_deltas(t.xf, t.yf, a, b);
+      Hit h;
+      h.sd = 0.f;
+      bool inside = false;
+      if (decltype(late)::value) {
+        if (!rec_depth<CLIP, true>(d, b, cc, e01, e12, e02, h, inside)) return;
+      } else {
+        if (!rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside)) return;
+        if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
+      }
+      const unsigned long long key = make_key(h.pz, __float_as_int(cc.y));
+      if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
+    };
+    if (dist_late)
+      pix_lists_walk<true, false>(ws, t, F, H, blur, out.box_shrink, P,
+                                  [&](bool have, int c) { body1(have, c, std::true_type()); });
+    else
+      pix_lists_walk<false, false>(ws, t, F, H, blur, out.box_shrink, P,
+                                   [&](bool have, int c) { body1(have, c, std::false_type()); });
+#else
+    bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
+      walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
+        if (!(in_box && t.valid)) return;
+        Hit h;
+        h.sd = 0.f;
+        bool inside = false;
+        if (dist_late) {
+          if (!test_face_depth<CLIP, true>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+        } else {
+          if (!test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+          if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
+        }
+        const unsigned long long key = make_key(h.pz, cd.fid);
+        if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
+      });
+    });
+#endif
+    k1_finish<CLIP, TEX>(ws, t, F, H, sigma, out, bestkey, bestsd, bestb0, bestb1, bestb2, dist_late);
   } else {
     // Per-pixel top-K list: K (depth|face) keys + their blend factors (1 - p), kept SORTED in
     // registers.  A new face is bubbled through the array with compare-exchanges on static
@@ -1632,7 +1629,12 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
           // the hard K = 1 render's candidate test for this pair (test_face_depth<true, true>): strictly inside,
           // depth from the CLIPPED barycentrics (h.c* hold the unclipped ones here), not negative.  Before the
           // K-th-key filter below: the nearest covering face need not be among the K nearest kept faces.
-          const bool cin = in_box && t.valid && inside;
+          // (a face that cannot win is dropped before the divisions: clipping an inside pixel's barycentrics divides
+          // them by their sum s = area / (area + kEps) -- above 1 for a back-facing face -- so pzc = pz / s up to
+          // rounding, and pz (1 - 1e-5) > best s means pzc > best.  With the walk roughly front to back this spares
+          // most of the back layer.  cbest still empty: its depth bits are a NaN and the comparison is false.)
+          const bool cin = in_box && t.valid && inside &&
+                           !(h.pz * 0.99999f > __uint_as_float((unsigned)(cbest >> 32)) * (h.c0 + h.c1 + h.c2));
           if (__ballot(cin) != 0ull) {
             float c0 = h.c0, c1 = h.c1, c2 = h.c2;
             clip_bary(c0, c1, c2);
@@ -1833,6 +1835,68 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? ACFM_K1_WAVES : 4) void k
 #endif
     if (!t.none) fwd_block<K, CLIP, TEX>(ws, t, F, H, blur, sigma, out, S);
     wave_lds_sync();   // the next block reuses the LDS lists
+  }
+}
+
+// Texture forward from the cover plane (ACFM_RECORD_COVER, acfm_tex_forward ws_ready = 2): the K-nearest render of this
+// geometry left the nearest covering face of every pixel of its work blocks in ws.cover -- same inside test, same
+// clipped depth, same tie-break as the K = 1 walk -- so a block is one dependent chain (id -> face record -> texel)
+// per pixel and no binning.  Same schedule as k_raster_fwd (the order's work entries, then a contiguous run of the
+// flagged-empty ones per wave); the unit is a WAVE of a four-wave workgroup and there is no LDS.  What is left is
+// mostly the constant stores of the ~80 % empty blocks (24 us by themselves at 64 frames @256^2).
+constexpr int COVER_WPB = 4;   // waves per workgroup
+template <bool CLIP>
+__global__ __launch_bounds__(64 * COVER_WPB) void k_tex_cover(RasterWs ws, int N, int F, int H, float sigma, FwdOut out) {
+  const int tiles = (H + RBLK - 1) / RBLK;
+  Sched sc;
+  sc.G = (N & 7) == 0 ? 8 : 1;
+  sc.per = (N / sc.G) * tiles * tiles;
+  sc.g = sc.G == 8 ? ((int)blockIdx.x & 7) : 0;
+  const int wg = sc.G == 8 ? ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  sc.j0 = wg * COVER_WPB + wave;
+  sc.stride = ((int)gridDim.x / sc.G) * COVER_WPB;
+  sc.n_work = ws.n_work[sc.g];
+  sc.e_end = sc.n_work;
+  sc.sub = -1;
+  const int lane = threadIdx.x & 63;
+  {
+    const int n_empty = sc.per - sc.n_work, chunk = (n_empty + sc.stride - 1) / sc.stride;
+    const int e0 = sc.n_work + sc.j0 * chunk, e1 = min(sc.per, e0 + chunk);
+    if ((H & (RBLK - 1)) == 0) {
+      const FillLane<1> fl = make_fill_lane<1>(H, lane);
+#pragma unroll 1
+      for (int e = e0; e < e1; ++e) {
+        int n, by, bx;
+        entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+        fwd_fill_block_whole<1, true>(out, n, by, bx, H, lane, fl);
+      }
+    } else {
+#pragma unroll 1
+      for (int e = e0; e < e1; ++e) {
+        int n, by, bx;
+        entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+        fwd_fill_block<1, true>(out, n, by, bx, H, lane);
+      }
+    }
+  }
+#pragma unroll 1
+  for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
+    const Tile t = make_tile(ws, sc, e, N, H, false);
+    unsigned long long bestkey = KEY_NONE;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (t.valid) {
+      const int f = out.cover_in[t.pix];
+      if (f >= 0) {
+        const FaceRec& r = ws.rec[(size_t)t.n * F + f];
+        const float4 ra = r.a, rb = r.b, rc = r.c;
+        Hit h;
+        bool inside = false;
+        test_face_depth<CLIP, true>(t.xf, t.yf, ra, rb, rc.x, rc.y, h, inside);
+        bestkey = make_key(h.pz, f); b0 = h.c0; b1 = h.c1; b2 = h.c2;
+      }
+    }
+    k1_finish<CLIP, true>(ws, t, F, H, sigma, out, bestkey, 0.f, b0, b1, b2, true);
   }
 }
 
@@ -2844,8 +2908,18 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
   }
   {
     ProfScope ps(ACFM_PROF_TEX_FWD, st);
-    hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
-                       0.f, sigma, out);
+    if (out.cover_in) {
+      // one wave per div entries of the order (measured at 64 frames @256^2, entries per wave 0.5 / 1 / 2 / 4 / 8:
+      // 47 / 35 / 31 / 43 / 45 us: fewer waves leave the stores of the empty blocks to too few issuers)
+      const size_t G = (N & 7) == 0 ? 8 : 1;
+      const size_t per = (size_t)((H + RBLK - 1) / RBLK) * ((H + RBLK - 1) / RBLK) * (N / G);
+      const size_t d = (size_t)(tn.div[1] < 1 ? 1 : tn.div[1]) * COVER_WPB;
+      hipLaunchKernelGGL((k_tex_cover<true>), dim3((unsigned)(G * ((per + d - 1) / d))), dim3(64 * COVER_WPB), 0, st, ws,
+                         N, F, H, sigma, out);
+    } else {
+      hipLaunchKernelGGL((k_raster_fwd<1, true, true>), dim3(tile_grid(N, H, tn.div[1])), dim3(RT), 0, st, ws, N, F, H,
+                         0.f, sigma, out);
+    }
     ACFM_CHECK_LAUNCH();
   }
   if (loss) {
