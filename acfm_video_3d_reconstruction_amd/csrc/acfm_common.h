@@ -173,16 +173,20 @@ __device__ __forceinline__ float div_by(float x, float y, float r) {
 }
 
 // PointLineDistanceForward: squared distance from p to segment ab.
+// tc (optional): the clamped segment parameter, 1 for a degenerate segment -- what PointLineDistanceBackward
+// recomputes with the same expression (the silhouette backward takes it from here instead).
 __device__ __forceinline__ float point_line_dist(float px, float py, float ax, float ay, float bx,
-                                                 float by) {
+                                                 float by, float* tc = nullptr) {
   const float bax = bx - ax, bay = by - ay;
   const float l2 = bax * bax + bay * bay;
   if (l2 <= ACFM_K_EPS) {
     const float dx = px - bx, dy = py - by;
+    if (tc) *tc = 1.0f;
     return dx * dx + dy * dy;
   }
   float t = div_by(bax * (px - ax) + bay * (py - ay), l2, recip_refined(l2));
   t = fminf(fmaxf(t, 0.0f), 1.0f);
+  if (tc) *tc = t;
   const float qx = ax + t * bax, qy = ay + t * bay;
   const float dx = qx - px, dy = qy - py;
   return dx * dx + dy * dy;
@@ -193,7 +197,7 @@ __device__ __forceinline__ float point_line_dist(float px, float py, float ax, f
 // component, so each half is bit-identical to point_line_dist.  Segments (ax, ay)-(bx, by), one per component.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f point_line_dist2(float px, float py, v2f ax, v2f ay, v2f bx, v2f by) {
+__device__ __forceinline__ v2f point_line_dist2(float px, float py, v2f ax, v2f ay, v2f bx, v2f by, v2f* tc = nullptr) {
   const v2f bax = bx - ax, bay = by - ay;
   const v2f l2 = bax * bax + bay * bay;
   const v2f num = bax * (px - ax) + bay * (py - ay);
@@ -212,6 +216,7 @@ __device__ __forceinline__ v2f point_line_dist2(float px, float py, v2f ax, v2f 
   const v2f de = ex * ex + ey * ey;
   d.x = l2.x <= ACFM_K_EPS ? de.x : d.x;
   d.y = l2.y <= ACFM_K_EPS ? de.y : d.y;
+  if (tc) { tc->x = l2.x <= ACFM_K_EPS ? 1.0f : t.x; tc->y = l2.y <= ACFM_K_EPS ? 1.0f : t.y; }
   return d;
 }
 

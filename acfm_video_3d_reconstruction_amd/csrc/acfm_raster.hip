@@ -843,15 +843,18 @@ __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4
   return !(pz < 0.0f);
 }
 
+// tpar (optional): the clamped segment parameters of the three edges (01, 02, 12), for the backward
 __device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4& A, const float4& B,
-                                               float blur, bool inside, Hit& h) {
+                                               float blur, bool inside, Hit& h, float* tpar = nullptr) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
   // edges 01 and 02 (both start at vertex 0) share the packed pipe, edge 12 goes through the scalar one
   const v2f ax = {x0, x0}, ay = {y0, y0}, bx = {A.z, A.w}, by = {B.x, B.y};
-  const v2f d2 = point_line_dist2(xf, yf, ax, ay, bx, by);
+  v2f t2;
+  const v2f d2 = point_line_dist2(xf, yf, ax, ay, bx, by, tpar ? &t2 : nullptr);
   h.d01 = d2.x;
   h.d02 = d2.y;
-  h.d12 = point_line_dist(xf, yf, x1, y1, x2, y2);
+  h.d12 = point_line_dist(xf, yf, x1, y1, x2, y2, tpar ? tpar + 2 : nullptr);
+  if (tpar) { tpar[0] = t2.x; tpar[1] = t2.y; }
   const float d = fminf(fminf(h.d01, h.d02), h.d12);
   h.sd = inside ? -d : d;
   return inside || !(d >= blur);
@@ -1914,19 +1917,12 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
   return v;
 }
 
-// PointLineDistanceBackward with the clamped t held constant
+// PointLineDistanceBackward with the clamped t held constant.  t is the forward's own clamped
+// parameter (point_line_dist, same expression; 1 for a degenerate segment: then q = b exactly, the gradient of a
+// is g 0 e = 0 and that of b is g 2 (b - p) = -2 (p - b) g, the degenerate branch of the reference bit for bit).
 __device__ __forceinline__ void point_line_dist_bwd(float px, float py, float ax, float ay, float bx,
-                                                    float by, float g, float& gax, float& gay,
+                                                    float by, float t, float g, float& gax, float& gay,
                                                     float& gbx, float& gby) {
-  const float bax = bx - ax, bay = by - ay;
-  const float l2 = bax * bax + bay * bay;
-  if (l2 <= ACFM_K_EPS) {
-    gax = 0.f; gay = 0.f;
-    gbx = -2.0f * (px - bx) * g; gby = -2.0f * (py - by) * g;
-    return;
-  }
-  float t = div_by(bax * (px - ax) + bay * (py - ay), l2, recip_refined(l2));
-  t = fminf(fmaxf(t, 0.0f), 1.0f);
   const float qx = (1.0f - t) * ax + t * bx, qy = (1.0f - t) * ay + t * by;
   const float ex = 2.0f * (qx - px), ey = 2.0f * (qy - py);
   gax = g * (1.0f - t) * ex; gay = g * (1.0f - t) * ey;
@@ -2019,7 +2015,8 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       member = member && test_face_depth<false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, h, inside);
       member = member && (make_key(h.pz, cd.fid) <= kthkey);
       if (__ballot(member) == 0ull) return;
-      if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h);
+      float tpar[3] = {0.f, 0.f, 0.f};
+      if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h, tpar);
       if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
       if (member) {
@@ -2035,8 +2032,9 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         const bool e02 = !e01 && h.d02 <= h.d01 && h.d02 <= h.d12;
         const float ax = (e01 || e02) ? x0 : x1, ay = (e01 || e02) ? y0 : y1;
         const float bx = e01 ? x1 : x2, by = e01 ? y1 : y2;
+        const float tq = e01 ? tpar[0] : (e02 ? tpar[1] : tpar[2]);
         float ax_, ay_, bx_, by_;
-        point_line_dist_bwd(t.xf, t.yf, ax, ay, bx, by, gd, ax_, ay_, bx_, by_);
+        point_line_dist_bwd(t.xf, t.yf, ax, ay, bx, by, tq, gd, ax_, ay_, bx_, by_);
         if (e01) { g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_; }
         else if (e02) { g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_; }
         else { g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_; }
