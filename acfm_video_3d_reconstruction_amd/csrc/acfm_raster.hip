@@ -1340,8 +1340,8 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
     }
   } else {
     if (valid) {
+      // (kth is left alone: the backward reads it only where mask != 0, and mask is 0 on this whole block)
       st_real(out.mask, pix, 0.0f, out.h16);
-      if (out.kth) out.kth[pix] = KEY_NONE;
       if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
     }
     if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
@@ -1409,8 +1409,7 @@ __device__ __forceinline__ void fwd_fill_block_whole(const FwdOut& out, int n, i
       out.tidx[pix] = -1;
     }
   } else {
-    st_real(out.mask, pix, 0.0f, out.h16);
-    if (out.kth) out.kth[pix] = KEY_NONE;
+    st_real(out.mask, pix, 0.0f, out.h16);   // (kth: see fwd_fill_block)
     if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
     if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
       const int tiles = H / RBLK;

@@ -247,7 +247,8 @@ typedef struct AcfmRasterTuning {
  *      plane (the K faces are still found and blended; it is the one slot the reference's
  *      callers read, loss_utils.py:214,431, and saves 8*(K-1) bytes per pixel of HBM writes)
  *   -> kth [N,H,H] u64 (optional, NULL to skip): state for acfm_sil_backward -- the
- *      (depth bits << 32 | face) key of the K-th kept face where K faces were kept, else ~0
+ *      (depth bits << 32 | face) key of the K-th kept face where K faces were kept, else ~0; defined where
+ *      mask != 0 (all the backward reads) -- the 8x8 blocks no face comes near are not written
  *   -> vis [N,V] u8 (optional): 1 for every vertex of a face that is nearest in some pixel,
  *      i.e. the visible-vertex set of loss_utils.bds_loss (:214-224), fused into the raster
  * K in {2,4,8,10,20,32}. */

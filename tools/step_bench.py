@@ -74,8 +74,8 @@ if not a.graph:                          # the hipEvent brackets are not part of
     torch.cuda.synchronize()
     prof = _lib.prof_collect(); lib.acfm_prof_enable(0)
     ks = sum(ms for ms, _ in prof.values()) / a.iters
-print(("hipGraph " if a.graph else "eager ") + "multiframe step B=%d T=2 G=%d (%d meshes) @%d, mesh=%s tex=%d: %.2f ms/step (%.0f clip-frames/s), HIP kernels %.2f ms" % (
-    B, G, G * N, H, a.mesh, a.tex, 1e3 * dt, N / dt, ks))
+print(("hipGraph " if a.graph else "eager ") + "multiframe step B=%d T=2 G=%d (%d meshes) @%d, mesh=%s tex=%d: %.2f ms/step (%.0f clip-frames/s)%s" % (
+    B, G, G * N, H, a.mesh, a.tex, 1e3 * dt, N / dt, "" if a.graph else ", HIP kernels %.2f ms" % ks))
 for k, (ms, c) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
     print("   %-24s %8.1f us/step  x%.0f" % (k, 1e3 * ms / a.iters, c / a.iters))
 
