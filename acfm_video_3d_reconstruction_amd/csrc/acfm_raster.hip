@@ -1862,7 +1862,53 @@ __global__ __launch_bounds__(64 * COVER_WPB) void k_tex_cover(RasterWs ws, int N
   sc.e_end = sc.n_work;
   sc.sub = -1;
   const int lane = threadIdx.x & 63;
-  {
+  // Empty blocks.  Images whose side is a multiple of 32, float storage: by QUADS of four horizontally adjacent
+  // blocks (32 x 8 pixels): a row of a quad is a whole 128-byte line of every 4-byte plane, so a plane of the quad
+  // is ONE 16-byte store per lane instead of four 4-byte ones whose 32-byte fragments have to meet in L2.  A block
+  // is empty iff its cost count is 0 (k_order's rule for the flag), read here by position instead of through the
+  // order; quads with a working block fall back to single-block fills.  Waves at the low end of the group fill,
+  // waves at the high end render (below), so that no wave queues both.
+  const bool quads = (H & 31) == 0 && !out.h16;
+  int work_j0 = sc.j0;
+  if (quads) {
+    const FillLane<1> fl = make_fill_lane<1>(H, lane);
+    const int qrow = tiles / 4, units = (N / sc.G) * tiles * qrow;
+    const size_t HW = (size_t)H * H;
+    const unsigned off4 = (unsigned)((lane >> 3) * H + (lane & 7) * 4);
+#pragma unroll 1
+    for (int u = sc.j0; u < units; u += sc.stride) {
+      const int m = u / (tiles * qrow), rem = u - m * (tiles * qrow);
+      const int byb = rem / qrow, bxb = (rem - byb * qrow) * 4;
+      const int n = m * sc.G + sc.g;
+      const int cnt = lane < 4 ? ws.tile_cnt[((size_t)n * tiles + byb) * tiles + bxb + lane] : 1;
+      const unsigned em = (unsigned)__ballot(cnt == 0) & 15u;
+      const int by = byb * RBLK, bx = bxb * RBLK;
+      if (em == 15u) {
+        const size_t pix0 = ((size_t)n * H + by) * H + bx;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* im = reinterpret_cast<float*>(out.imgs) + pix0 + (size_t)n * 2 * HW + off4;
+        *reinterpret_cast<float4*>(im) = z;
+        *reinterpret_cast<float4*>(im + HW) = z;
+        *reinterpret_cast<float4*>(im + 2 * HW) = z;
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out.sil) + pix0 + off4) = z;
+        *reinterpret_cast<int4*>(out.tidx + pix0 + off4) = make_int4(-1, -1, -1, -1);
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        ll2 v; v.x = -1; v.y = -1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = lane + 64 * j;               // 16-byte piece of the quad's 8 rows x 256 bytes of ids
+          *reinterpret_cast<ll2*>(reinterpret_cast<int64_t*>(out.p2f) + pix0 + (size_t)(i >> 4) * H + 2 * (i & 15)) = v;
+        }
+        if (out.lpart && lane < 4)
+          out.lpart[(((size_t)n * tiles + byb) * tiles + bxb + lane) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll 1
+        for (int b = 0; b < 4; ++b)
+          if ((em >> b) & 1u) fwd_fill_block_whole<1, true>(out, n, by, bx + b * RBLK, H, lane, fl);
+      }
+    }
+    work_j0 = sc.stride - 1 - sc.j0;
+  } else {
     const int n_empty = sc.per - sc.n_work, chunk = (n_empty + sc.stride - 1) / sc.stride;
     const int e0 = sc.n_work + sc.j0 * chunk, e1 = min(sc.per, e0 + chunk);
     if ((H & (RBLK - 1)) == 0) {
@@ -1883,7 +1929,7 @@ __global__ __launch_bounds__(64 * COVER_WPB) void k_tex_cover(RasterWs ws, int N
     }
   }
 #pragma unroll 1
-  for (int e = sc.j0; e < sc.e_end; e += sc.stride) {
+  for (int e = work_j0; e < sc.e_end; e += sc.stride) {
     const Tile t = make_tile(ws, sc, e, N, H, false);
     unsigned long long bestkey = KEY_NONE;
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
