@@ -2084,19 +2084,27 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         else if (e02) { g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_; }
         else { g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_; }
       }
-      // the 16 lanes of a row share the face: sum their contributions, lane 15 of the row adds
-      g0x = row_sum_dpp(g0x); g0y = row_sum_dpp(g0y);
-      g1x = row_sum_dpp(g1x); g1y = row_sum_dpp(g1y);
-      g2x = row_sum_dpp(g2x); g2y = row_sum_dpp(g2y);
-      // (a row without a face this iteration, or without members, sums to exact zeros)
-      if ((t.lane & 15) == 15) {
-        AccT* acc = s_acc[cd.idx];   // two groups can hold the same face in one iteration: atomics
-        if (g0x != 0.f) acc_add(&acc[0], g0x);
-        if (g0y != 0.f) acc_add(&acc[1], g0y);
-        if (g1x != 0.f) acc_add(&acc[2], g1x);
-        if (g1y != 0.f) acc_add(&acc[3], g1y);
-        if (g2x != 0.f) acc_add(&acc[4], g2x);
-        if (g2y != 0.f) acc_add(&acc[5], g2y);
+      // The 16 lanes of a row share the face: sum their six contributions.  First the two lanes of a pair swap
+      // halves -- the even lane keeps (g0x, g0y, g1x) of both, the odd lane (g1y, g2x, g2y) -- then three values
+      // instead of six go through the row shifts (by 2, 4, 8: lanes of one parity): 6 selects + 12 DPP adds instead
+      // of 24, and lanes 14 and 15 of the row add three sums each.  A fixed tree: deterministic.
+      {
+        const bool odd = (t.lane & 1) != 0;
+        float k0 = odd ? g1y : g0x, k1 = odd ? g2x : g0y, k2 = odd ? g2y : g1x;
+        const float s0 = odd ? g0x : g1y, s1 = odd ? g0y : g2x, s2 = odd ? g1x : g2y;
+#define ACFM_DPP_GET(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+        k0 += ACFM_DPP_GET(s0, 0xb1); k1 += ACFM_DPP_GET(s1, 0xb1); k2 += ACFM_DPP_GET(s2, 0xb1);   // quad_perm:[1,0,3,2]
+        k0 += ACFM_DPP_GET(k0, 0x112); k1 += ACFM_DPP_GET(k1, 0x112); k2 += ACFM_DPP_GET(k2, 0x112); // row_shr:2
+        k0 += ACFM_DPP_GET(k0, 0x114); k1 += ACFM_DPP_GET(k1, 0x114); k2 += ACFM_DPP_GET(k2, 0x114); // row_shr:4
+        k0 += ACFM_DPP_GET(k0, 0x118); k1 += ACFM_DPP_GET(k1, 0x118); k2 += ACFM_DPP_GET(k2, 0x118); // row_shr:8
+#undef ACFM_DPP_GET
+        // (a row without a face this iteration, or without members, sums to exact zeros)
+        if ((t.lane & 15) >= 14) {
+          AccT* acc = s_acc[cd.idx] + (odd ? 3 : 0);   // two groups can hold the same face in one iteration: atomics
+          if (k0 != 0.f) acc_add(&acc[0], k0);
+          if (k1 != 0.f) acc_add(&acc[1], k1);
+          if (k2 != 0.f) acc_add(&acc[2], k2);
+        }
       }
     });
     wave_lds_sync();
