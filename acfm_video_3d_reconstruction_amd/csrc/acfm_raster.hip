@@ -26,8 +26,11 @@
 //   * forward, K = 1 (blur 0): only the winner's edge distances are evaluated; 6-7 waves per SIMD.
 //   * backward: the same walk; membership of a face in a pixel's top-K is `key <= kth[pixel]`
 //     (kth saved by the forward), gradients of a candidate are summed over the 16 lanes of its
-//     group with DPP row shifts and ONE lane adds them to the candidate's LDS accumulator, which
-//     is flushed with one global float atomic per touched coordinate.  23 waves per CU.
+//     group (pair swap, then DPP row shifts on three values per lane) and TWO lanes add them to the
+//     candidate's LDS accumulator, which is flushed with one global float atomic per touched
+//     coordinate.  23 waves per CU.
+//   * forward, K > 1, ACFM_RECORD_COVER: the walk also keeps the nearest COVERING face per pixel (the
+//     hard K = 1 render's answer); k_tex_cover shades the texture render of the same geometry from it.
 //   * workgroups are dealt so that all blocks of a mesh run on one XCD (its face records stay
 //     in that XCD's L2).
 //   * k_tex_bwd_faces: the atlas gradient as a per-face gather over the face's box (no global
