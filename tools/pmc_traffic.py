@@ -5,7 +5,7 @@ The workload arguments are those of the profiled run (bench.py compares them wit
 import argparse, json, re
 
 NAMES = [("k_raster_fwd<20, false, false>", "k_raster_fwd<K,soft>"), ("k_sil_bwd", "k_sil_bwd"),
-         ("k_raster_fwd<1, true, true>", "k_raster_fwd<1,tex>"), ("k_tex_bwd", "k_tex_bwd"),
+         ("k_raster_fwd<1, true, true>", "k_raster_fwd<1,tex>"), ("k_tex_cover", "k_tex_cover"), ("k_tex_bwd", "k_tex_bwd"),
          ("k_mask_losses_bwd", "k_mask_losses_bwd"), ("k_mask_losses", "k_mask_losses"),
          ("k_setup", "k_setup"), ("k_tex_mse_bwd", "k_tex_mse_bwd"), ("k_tex_mse", "k_tex_mse"),
          ("k_sil_loss_finish1", "k_sil_loss_finish1"), ("k_tex_loss_finish1", "k_tex_loss_finish1")]
