@@ -492,22 +492,24 @@ template <int CAP_>
 struct CandListT {
   static constexpr int CAP = CAP_;
   float4 box[CAP_], a[CAP_], b[CAP_];
-  float2 c[CAP_];    // (z2, area)
+  float2 c[CAP_];    // (z2, denom = area + kEps)
+  float rden[CAP_];  // refined 1 / denom
   int fid[CAP_];
-  unsigned short sub[4][CAP_]; // per 16-lane group: candidates meeting its 4x4 pixels
+  unsigned char sub[4][CAP_];  // per 16-lane group: candidates meeting its 4x4 pixels (list positions < CAP <= 256)
 };
 
 
 struct Cand {
   float4 box, a, b;
-  float2 c;
+  float2 c;      // (z2, denom = area + kEps)
+  float rden;    // refined 1 / denom (k_setup's, the very operations the per-pixel code used to repeat)
   int fid, idx;
 };
 
 template <class LT>
 __device__ __forceinline__ Cand load_cand(const LT& L, int i) {
   Cand r;
-  r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i]; r.c = L.c[i]; r.fid = L.fid[i]; r.idx = i;
+  r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i]; r.c = L.c[i]; r.rden = L.rden[i]; r.fid = L.fid[i]; r.idx = i;
   return r;
 }
 
@@ -561,7 +563,8 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   const float xa1 = pix_to_ndc(H - 1 - (bx + 4), H), xi1 = pix_to_ndc(H - 1 - (bx + 7), H);
   const float ya0 = pix_to_ndc(H - 1 - by, H), yi0 = pix_to_ndc(H - 1 - (by + 3), H);
   const float ya1 = pix_to_ndc(H - 1 - (by + 4), H), yi1 = pix_to_ndc(H - 1 - (by + 7), H);
-  unsigned short* sub0 = L.sub[0];
+  static_assert(LT::CAP <= 256, "sub-list entries are bytes");
+  unsigned char* sub0 = L.sub[0];
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
   const bool split = t.sub >= 0;
@@ -581,10 +584,10 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
       }
       const unsigned long long b0 = __ballot(hx0 & hy0), b1 = __ballot(hx1 & hy0);
       const unsigned long long b2 = __ballot(hx0 & hy1), b3 = __ballot(hx1 & hy1);
-      if (hx0 & hy0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (hx1 & hy0) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (hx0 & hy1) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (hx1 & hy1) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (hx0 & hy0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned char)c;
+      if (hx1 & hy0) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned char)c;
+      if (hx0 & hy1) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned char)c;
+      if (hx1 & hy1) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned char)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   } else {
@@ -657,10 +660,10 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
       }
       const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
       const unsigned long long b2 = __ballot(k2), b3 = __ballot(k3);
-      if (k0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned short)c;
-      if (k1) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned short)c;
-      if (k2) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned short)c;
-      if (k3) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned short)c;
+      if (k0) sub0[0 * LT::CAP + n0 + __popcll(b0 & lt)] = (unsigned char)c;
+      if (k1) sub0[1 * LT::CAP + n1 + __popcll(b1 & lt)] = (unsigned char)c;
+      if (k2) sub0[2 * LT::CAP + n2 + __popcll(b2 & lt)] = (unsigned char)c;
+      if (k3) sub0[3 * LT::CAP + n3 + __popcll(b3 & lt)] = (unsigned char)c;
       n0 += __popcll(b0); n1 += __popcll(b1); n2 += __popcll(b2); n3 += __popcll(b3);
     }
   }
@@ -670,7 +673,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int my_n = (grp == 0) ? n0 : (grp == 1) ? n1 : (grp == 2) ? n2 : n3;
-  const unsigned short* sub = sub0 + grp * LT::CAP;
+  const unsigned char* sub = sub0 + grp * LT::CAP;
   // a group that has run out of faces (or has none) keeps loading its last (or the tile's
   // first) record: harmless, the lanes are masked by `have`.  (Prefetching the next record one
   // iteration ahead was measured: +16 VGPRs, no change in time.)
@@ -786,7 +789,8 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
         L.a[pos] = ws.rec[o].a;
         L.b[pos] = ws.rec[o].b;
         const float4 c4 = ws.rec[o].c;
-        L.c[pos] = make_float2(c4.x, c4.y);
+        L.c[pos] = make_float2(c4.x, c4.z);
+        L.rden[pos] = c4.w;
         L.fid[pos] = f;
       }
       list_n += __popcll(bal);
@@ -827,12 +831,11 @@ __device__ __forceinline__ float bary_depth(float c0, float c1, float c2, float 
 
 template <bool CLIP, bool INSIDE_ONLY = false>
 __device__ __forceinline__ bool test_face_depth(float xf, float yf, const float4& A, const float4& B,
-                                                float z2, float area, Hit& h, bool& inside) {
+                                                float z2, float denom, float r, Hit& h, bool& inside) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
   const float z0 = B.z, z1 = B.w;
-  const float denom = area + ACFM_K_EPS;
-  // three IEEE divisions by the same denominator share one refined reciprocal (acfm_common.h)
-  const float r = recip_refined(denom);
+  // three IEEE divisions by the same denominator denom = area + kEps share one refined reciprocal r (acfm_common.h),
+  // both computed once per face by k_setup (FaceRec.c) with these very operations
   auto div = [&](float x) { return div_by(x, denom, r); };
   const float w0 = div(edge_fn(xf, yf, x1, y1, x2, y2));
   const float w1 = div(edge_fn(xf, yf, x2, y2, x0, y0));
@@ -865,9 +868,9 @@ __device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4&
 
 template <bool CLIP>
 __device__ __forceinline__ bool test_face(float xf, float yf, const float4& A, const float4& B,
-                                          float z2, float area, float blur, Hit& h) {
+                                          float z2, float denom, float rden, float blur, Hit& h) {
   bool inside;
-  if (!test_face_depth<CLIP>(xf, yf, A, B, z2, area, h, inside)) return false;
+  if (!test_face_depth<CLIP>(xf, yf, A, B, z2, denom, rden, h, inside)) return false;
   return test_face_dist(xf, yf, A, B, blur, inside, h);
 }
 
@@ -1567,9 +1570,9 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         h.sd = 0.f;
         bool inside = false;
         if (dist_late) {
-          if (!test_face_depth<CLIP, true>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+          if (!test_face_depth<CLIP, true>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, cd.rden, h, inside)) return;
         } else {
-          if (!test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside)) return;
+          if (!test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, cd.rden, h, inside)) return;
           if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
         }
         const unsigned long long key = make_key(h.pz, cd.fid);
@@ -1629,7 +1632,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         Hit h;
         bool inside = false;
         bool live = in_box && t.valid &&
-                    test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, h, inside);
+                    test_face_depth<CLIP>(t.xf, t.yf, cd.a, cd.b, cd.c.x, cd.c.y, cd.rden, h, inside);
         if (out.cover_out) {
           // the hard K = 1 render's candidate test for this pair (test_face_depth<true, true>): strictly inside,
           // depth from the CLIPPED barycentrics (h.c* hold the unclipped ones here), not negative.  Before the
@@ -1943,7 +1946,7 @@ __global__ __launch_bounds__(64 * COVER_WPB) void k_tex_cover(RasterWs ws, int N
         const float4 ra = r.a, rb = r.b, rc = r.c;
         Hit h;
         bool inside = false;
-        test_face_depth<CLIP, true>(t.xf, t.yf, ra, rb, rc.x, rc.y, h, inside);
+        test_face_depth<CLIP, true>(t.xf, t.yf, ra, rb, rc.x, rc.z, rc.w, h, inside);
         bestkey = make_key(h.pz, f); b0 = h.c0; b1 = h.c1; b2 = h.c2;
       }
     }
@@ -2060,7 +2063,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       bool inside = false;
       // stage 1 (depth): only faces at or before the pixel's K-th kept face took part in the
       // blend; the others are dropped before their edge distances are computed
-      member = member && test_face_depth<false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, h, inside);
+      member = member && test_face_depth<false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, cd.rden, h, inside);
       member = member && (make_key(h.pz, cd.fid) <= kthkey);
       if (__ballot(member) == 0ull) return;
       float tpar[3] = {0.f, 0.f, 0.f};
