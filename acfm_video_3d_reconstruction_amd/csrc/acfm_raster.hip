@@ -492,9 +492,7 @@ template <int CAP_>
 struct CandListT {
   static constexpr int CAP = CAP_;
   float4 box[CAP_], a[CAP_], b[CAP_];
-  float2 c[CAP_];    // (z2, denom = area + kEps)
-  float rden[CAP_];  // refined 1 / denom
-  int fid[CAP_];
+  float4 c[CAP_];    // (z2, denom = area + kEps, refined 1 / denom, face id as bits)
   unsigned char sub[4][CAP_];  // per 16-lane group: candidates meeting its 4x4 pixels (list positions < CAP <= 256)
 };
 
@@ -509,7 +507,9 @@ struct Cand {
 template <class LT>
 __device__ __forceinline__ Cand load_cand(const LT& L, int i) {
   Cand r;
-  r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i]; r.c = L.c[i]; r.rden = L.rden[i]; r.fid = L.fid[i]; r.idx = i;
+  r.box = L.box[i]; r.a = L.a[i]; r.b = L.b[i];
+  const float4 c = L.c[i];   // one 16-byte read
+  r.c = make_float2(c.x, c.y); r.rden = c.z; r.fid = __float_as_int(c.w); r.idx = i;
   return r;
 }
 
@@ -789,9 +789,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
         L.a[pos] = ws.rec[o].a;
         L.b[pos] = ws.rec[o].b;
         const float4 c4 = ws.rec[o].c;
-        L.c[pos] = make_float2(c4.x, c4.z);
-        L.rden[pos] = c4.w;
-        L.fid[pos] = f;
+        L.c[pos] = make_float4(c4.x, c4.z, c4.w, __int_as_float(f));
       }
       list_n += __popcll(bal);
     }
@@ -2119,7 +2117,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       const AccT z = (AccT)0;
       const AccT a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
       if (a0 != z || a1 != z || a2 != z || a3 != z || a4 != z || a5 != z) {
-        const int4 vi = ws.vidx[(size_t)t.n * F + L.fid[c]];
+        const int4 vi = ws.vidx[(size_t)t.n * F + __float_as_int(L.c[c].w)];
         if (a0 != z) acc_add_raw(&gout[2 * vi.x], a0);
         if (a1 != z) acc_add_raw(&gout[2 * vi.x + 1], a1);
         if (a2 != z) acc_add_raw(&gout[2 * vi.y], a2);
