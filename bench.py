@@ -154,6 +154,8 @@ def main():
     if cfg5:   # references and atlas held in half by the caller (what ACFM_STORE_F16 reads); the atlas gradient stays float
         gt_h, edt_h, imgs_h = gt_mask.half(), edt.half(), imgs_gt.half()
 
+    seed = torch.ones((), device=dev)   # d total / d total, made once (autograd.grad would fill a fresh one every step)
+
     def compute(ren, fused=False):
         pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
         if cfg5:
@@ -161,7 +163,7 @@ def main():
             bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
             tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_h, gt_h)[0]
             total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
-            g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params)
+            g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, grad_outputs=seed)
             if world > 1:
                 flat_views[0].copy_(g_mean)
                 flat_extra.copy_(total.detach().reshape(1))
@@ -200,7 +202,7 @@ def main():
             total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1])
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
-        g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, allow_unused=not a.tex)
+        g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, grad_outputs=seed, allow_unused=not a.tex)
         if world > 1:
             # the step writes its shared gradient and loss scalar straight into the exchange buffer (the
             # last two nodes of the captured graph): the exchange itself is then one RCCL launch
@@ -399,7 +401,7 @@ def main():
             tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
             cur_s.wait_stream(prior_s)
             total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5]) + prior
-            return torch.autograd.grad(total, params2)
+            return torch.autograd.grad(total, params2, grad_outputs=seed)
         full_fn, full_mode = full_step, "eager launches"
         if not a.eager:
             try:                                   # the same step as one hipGraph (forward + backward, static shapes)
