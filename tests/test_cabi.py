@@ -67,3 +67,32 @@ def test_product_does_not_import_oracle():
                 assert "libacfm_oracle" not in src, fn
                 assert '#include "../../oracle' not in src and "oracle/acfm_oracle" not in src.replace(
                     "oracle/acfm_oracle.c is the bit-level spec", ""), fn
+
+
+def test_cover_flag_policy_and_tuning_helpers():
+    """ACFM_RECORD_COVER is decided on the host (ops._cover_tuning / _cover_taken): off until a texture render has taken
+    a silhouette render's workspace over, off again once a recorded plane went unread; raster_tuning(record_cover=...)
+    forces it; the helpers never mutate the caller's structure and keep the other flag bits."""
+    import torch
+    from acfm_video_3d_reconstruction_amd import _lib, ops
+    dev = torch.device("cpu")          # the policy is pure host logic: any hashable device key
+    ops._COVER.pop(dev, None)
+    flag = lambda t: bool(t is not None and t.flags & 4)
+    assert not flag(ops._cover_tuning(dev, None))                 # nothing seen yet
+    assert ops._cover_taken(dev, None) == 1                       # taken over, but no plane was recorded
+    t = ops._cover_tuning(dev, None)
+    assert flag(t) and ops._cover_taken(dev, t) == 2              # recorded and read
+    assert flag(ops._cover_tuning(dev, None))
+    assert not flag(ops._cover_tuning(dev, None))                 # the previous plane was never read
+    assert not flag(ops._cover_tuning(dev, None))
+    # forced either way, whatever the state; the deterministic / f16 bits survive
+    with _lib.raster_tuning(deterministic=True, record_cover=True) as rt:
+        t = ops._cover_tuning(dev, rt.t)
+        assert t.flags == 5 and rt.t.flags == 1
+        t16 = _lib.with_f16(t, True)
+        assert t16.flags == 7 and t.flags == 5
+    with _lib.raster_tuning(record_cover=False) as rt:
+        ops._COVER[dev] = {"on": True, "pending": False}
+        assert not flag(ops._cover_tuning(dev, rt.t))
+    assert _lib.with_cover(None, False) is None and _lib.with_cover(None, True).flags == 4
+    ops._COVER.pop(dev, None)
