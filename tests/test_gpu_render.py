@@ -529,6 +529,49 @@ def test_hip_graph_capture_and_replay(meshes):
     np.testing.assert_array_equal(m2.cpu().numpy(), m3.cpu().numpy())
 
 
+def test_cover_plane_inside_a_hip_graph(meshes):
+    """The silhouette render + the texture render that shades from its cover plane, captured into one hipGraph: the
+    plane lives in the captured workspace, so a replay after an in-place update of the static inputs renders the new
+    geometry -- same ids and images as eager renders of the new inputs, with or without the plane."""
+    from acfm_video_3d_reconstruction_amd import ops, _lib
+    d = _dev()
+    verts, f, cams = _setup(meshes, "bird", 8, 95)
+    H = 96
+    tv, tc = torch.tensor(verts, device=d), torch.tensor(cams, device=d)
+    faces = torch.from_numpy(f)[None].to(d).expand(8, -1, -1)
+    atlas = torch.rand((8, f.shape[0], 3, 3, 3), device=d)
+
+    def step():
+        with _lib.raster_tuning(record_cover=True):
+            m, p = ops.sil_render(tv, faces, tc, H, k_out=1)
+            hit = ops._shared_setup(tv, tc, ops.expand_faces(faces, 8), H, 0.0)
+            assert hit is not None and hit[3].flags & 4
+            return (m, p) + tuple(ops.tex_render(tv, faces, tc, atlas, H))
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = step()
+    for moved in (False, True):
+        if moved:
+            with torch.no_grad():
+                tc[:, 1] += 0.07
+                tv += 0.003
+        g.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in outs]
+        ops._SETUP.clear()
+        with _lib.raster_tuning(record_cover=False):
+            ref = ops.sil_render(tv, faces, tc, H, k_out=1) + tuple(ops.tex_render(tv, faces, tc, atlas, H))
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        assert (got[4] >= 0).any()
+
+
 def test_silhouette_backward_twice_on_one_workspace(meshes):
     """The raster workspace's NDC-gradient scratch is cleared by the face setup and again by every
     backward that reads it (no zero-fill launch of its own): a second backward through the same
