@@ -58,8 +58,9 @@ def fused_silhouette_losses(mask_pred, mask_gt, edt, eps=1e-6, raw=False):
     for combine_losses (no column views, no IoU division: nothing but the one launch)."""
     N = mask_pred.shape[0]
     # mask_gt / edt may be [N/G, ...]: the ground truth of a frame shared by its G hypotheses
-    out = ops.mask_losses(mask_pred.reshape(N, -1), mask_gt.reshape(mask_gt.shape[0], -1),
-                          edt.reshape(edt.shape[0], -1))
+    # (the mask goes in as it is, not as a [N, H W] view: its gradient then reaches the render's backward unformed --
+    # ops.LazyGrad -- and that kernel forms it per pixel instead of reading a [N,H,W] image of it)
+    out = ops.mask_losses(mask_pred, mask_gt.reshape(mask_gt.shape[0], -1), edt.reshape(edt.shape[0], -1))
     if raw:
         return out
     return out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]

@@ -15,6 +15,8 @@ SIL_BLUR = math.log(1.0 / 1e-4 - 1.0) * 1e-4  # nmr.py:157
 
 
 def _f32c(t):
+    if type(t) is LazyGrad:          # (defined below) a gradient another operator of this module has not formed yet
+        t = t.materialize()
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -606,6 +608,59 @@ def _lazy_pix_to_face(plane0, vis, v, f, c, H, K, blur, sigma, offset_z):
     return p
 
 
+# The reference computes its losses on the rendered images with separate operators (main.py:644-662, 716-717), so the
+# gradient of a loss with respect to a whole image -- [N,H,W] for the silhouette terms, [N,3,H,W] for the texture
+# MSE -- is written by one kernel only to be read once by the render's backward.  Both backward kernels can form that
+# gradient per pixel themselves (acfm_sil_loss_backward, acfm_tex_mse_backward_faces: the opt-in fused operators).
+# LazyGrad lets the drop-in operators use them too: the loss operator's backward hands autograd a tensor of the right
+# shape that merely REMEMBERS how the gradient is defined (the operator's inputs and its upstream gradient); the render's
+# backward recognises it -- same image, untouched -- and calls the fused kernel; ANY other use of it (a hook, a second
+# consumer whose gradient autograd adds to it, torch.autograd.grad with respect to the image itself) forms the
+# gradient with the loss operator's own backward kernel first and then behaves like the plain tensor.
+LAZY_GRADS = [True]
+
+
+class LazyGrad(torch.Tensor):
+    @staticmethod
+    def __new__(cls, like, tag, payload, make_full):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(like.shape), dtype=like.dtype, device=like.device)
+        r._tag, r._payload, r._make_full, r._full = tag, payload, make_full, None
+        return r
+
+    @property
+    def is_materialized(self):
+        return self._full is not None
+
+    def materialize(self):
+        if self._full is None:
+            self._full = self._make_full()
+            self._make_full = self._payload = None
+        return self._full
+
+    def take(self, tag, image):
+        """The operator inputs behind this gradient if it is still unformed, of kind `tag`, and a gradient with
+        respect to exactly `image` (same storage, shape and version); else None."""
+        if self._full is not None or self._tag != tag:
+            return None
+        img = self._payload[0]
+        if img.data_ptr() != image.data_ptr() or img.shape != image.shape or img._version != image._version:
+            return None
+        return self._payload
+
+    def __repr__(self):
+        return "LazyGrad(%s, shape=%s, materialized=%s)" % (self._tag, tuple(self.shape), self.is_materialized)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default) and type(args[0]) is LazyGrad \
+                and args[0]._full is None:
+            return args[0]
+        from torch.utils._pytree import tree_map
+        unwrap = lambda x: x.materialize() if type(x) is LazyGrad else x
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
+
+
 # ------------------------------------------------------------------------------ silhouette
 class _SilRender(torch.autograd.Function):
     @staticmethod
@@ -648,10 +703,19 @@ class _SilRender(torch.autograd.Function):
         F = f.shape[1]
         if gmask is None:
             return (None,) * 10
-        g = _f32c(gmask)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
         ws, nb, tune = ctx.ws
+        pay = gmask.take("mask_losses", mask) if type(gmask) is LazyGrad else None
+        if pay is not None:      # the silhouette losses' gradient, still unformed: the backward kernel forms it per pixel
+            _m, lg, le, rb, go = pay
+            with torch.cuda.device(v.device):
+                _lib.check(_lib.lib().acfm_sil_loss_backward(
+                    _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(lg), _lib.ptr(le), rb,
+                    _lib.ptr(go), N, V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
+                    _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_loss_backward")
+            return (gv, None, gc) + (None,) * 7
+        g = _f32c(gmask)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_sil_backward(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
@@ -823,7 +887,9 @@ class _TexRender(torch.autograd.Function):
         ctx.save_for_backward(tidx)
         ctx.cfg = (N, F, H, R, NA, V)
         ctx.adt = atlas.dtype
+        ctx.tune, ctx.f16 = tune, f16
         ctx.ws = (ws, nb, float(ws_blur))   # face boxes: the gather form of the atlas gradient walks them
+        ctx.imgs_ref = (imgs.data_ptr(), imgs.shape)   # (to recognise a LazyGrad of this very image in the backward)
         ctx.mark_non_differentiable(sil, p2f)
         ctx.set_materialize_grads(False)
         return imgs, sil, p2f
@@ -833,7 +899,22 @@ class _TexRender(torch.autograd.Function):
         (tidx,) = ctx.saved_tensors
         N, F, H, R, NA, V = ctx.cfg
         ga = None
-        if ctx.needs_input_grad[3] and gimgs is not None:
+        pay = None
+        if ctx.needs_input_grad[3] and type(gimgs) is LazyGrad and TEX_BWD_GATHER and R <= 8 and not ctx.f16 and \
+                gimgs._full is None and gimgs._tag == "tex_mse":
+            t0 = gimgs._payload[0]
+            if (t0.data_ptr(), t0.shape) == ctx.imgs_ref:
+                pay = gimgs._payload
+        if pay is not None:      # the texture MSE's gradient, still unformed: the atlas-gradient kernel forms it per pixel
+            t0, ri, rm, rb, go = pay
+            ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=t0.device)
+            ws, nb, ws_blur = ctx.ws
+            with torch.cuda.device(t0.device):
+                _lib.check(_lib.lib().acfm_tex_mse_backward_faces(
+                    _lib.ptr(t0), _lib.ptr(ri), _lib.ptr(rm), rb, _lib.ptr(go), _lib.ptr(tidx), _lib.ptr(ws), nb,
+                    ws_blur, N, V, F, H, R, NA, _lib.ptr(ga), _lib.tuning_ptr(ctx.tune), _lib.cur_stream(t0.device)),
+                    "acfm_tex_mse_backward_faces")
+        elif ctx.needs_input_grad[3] and gimgs is not None:
             g = _f32c(gimgs)
             ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=g.device)
             ws, nb, ws_blur = ctx.ws
@@ -1002,13 +1083,19 @@ class _MaskLosses(torch.autograd.Function):
         N = m.shape[0]
         HW = m[0].numel()
         go = _f32c(gout)
-        gm = torch.empty_like(m)
-        with torch.cuda.device(m.device):
-            _lib.check(_lib.lib().acfm_mask_losses_backward(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e),
-                                                            _lib.ptr(go), N, HW, ctx.rb, _lib.ptr(gm),
-                                                            _lib.cur_stream(m.device)),
-                       "acfm_mask_losses_backward")
-        return gm, None, None
+        rb = ctx.rb
+
+        def make():
+            gm = torch.empty_like(m)
+            with torch.cuda.device(m.device):
+                _lib.check(_lib.lib().acfm_mask_losses_backward(_lib.ptr(m), _lib.ptr(g), _lib.ptr(e),
+                                                                _lib.ptr(go), N, HW, rb, _lib.ptr(gm),
+                                                                _lib.cur_stream(m.device)),
+                           "acfm_mask_losses_backward")
+            return gm
+        if LAZY_GRADS[0] and m.dim() == 3 and m.shape[1] == m.shape[2]:
+            return LazyGrad(m, "mask_losses", (m, g, e, rb, go), make), None, None
+        return make(), None, None
 
 
 def mask_losses(mask, gt=None, edt=None):
@@ -1041,12 +1128,18 @@ class _TexMSE(torch.autograd.Function):
         N = t.shape[0]
         HW = m[0].numel()
         g = _f32c(go)
-        gt = torch.empty_like(t)
-        with torch.cuda.device(t.device):
-            _lib.check(_lib.lib().acfm_tex_mse_backward(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), _lib.ptr(g),
-                                                        N, HW, ctx.rb, _lib.ptr(gt), _lib.cur_stream(t.device)),
-                       "acfm_tex_mse_backward")
-        return gt, None, None
+        rb = ctx.rb
+
+        def make():
+            gt = torch.empty_like(t)
+            with torch.cuda.device(t.device):
+                _lib.check(_lib.lib().acfm_tex_mse_backward(_lib.ptr(t), _lib.ptr(i), _lib.ptr(m), _lib.ptr(g),
+                                                            N, HW, rb, _lib.ptr(gt), _lib.cur_stream(t.device)),
+                           "acfm_tex_mse_backward")
+            return gt
+        if LAZY_GRADS[0]:
+            return LazyGrad(t, "tex_mse", (t, i, m, rb, g), make), None, None
+        return make(), None, None
 
 
 def tex_mse(tex, img, mask):

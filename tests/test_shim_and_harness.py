@@ -224,3 +224,32 @@ def test_lazy_pix_to_face_dispatch():
     assert torch.equal(p + 0, full) and int((p >= 0).sum()) == full.numel() and torch.equal(p[..., 0], full[..., 0])
     assert torch.equal(p.reshape(-1, K), full.reshape(-1, K))
     assert len(calls) == 1                                     # ... once
+
+
+def test_lazy_grad_dispatch():
+    """ops.LazyGrad (an image gradient a loss operator has not formed yet): take() hands the operator inputs to the
+    render's backward only for the very image (storage, shape, version) and kind; detach() keeps it unformed; any
+    other operation forms it exactly once and then behaves like the tensor."""
+    import torch
+    from acfm_video_3d_reconstruction_amd.ops import LazyGrad
+    img = torch.rand(2, 4, 4)
+    grad = torch.rand(2, 4, 4)
+    calls = []
+
+    def make():
+        calls.append(1)
+        return grad
+    g = LazyGrad(img, "mask_losses", (img, None, None, 2, torch.ones(2, 4)), make)
+    assert tuple(g.shape) == (2, 4, 4) and g.dtype == torch.float32 and not g.is_materialized
+    assert g.take("tex_mse", img) is None and g.take("mask_losses", img.clone()) is None
+    assert g.take("mask_losses", img.detach())[0] is img and g.detach() is g and not calls
+    other = torch.rand(2, 4, 4)
+    assert torch.equal(g + other, grad + other) and len(calls) == 1 and g.is_materialized     # e.g. autograd adding a second gradient
+    assert g.take("mask_losses", img) is None                                                # formed: the plain path from now on
+    assert torch.equal(g * 2, grad * 2) and torch.equal(g.reshape(2, -1), grad.reshape(2, -1)) and len(calls) == 1
+    img2 = torch.rand(2, 4, 4)
+    g2 = LazyGrad(img2, "mask_losses", (img2, None, None, 2, None), lambda: grad)
+    img2.add_(1.0)                                                                            # the image changed under the gradient
+    assert g2.take("mask_losses", img2) is not None          # (same version counter object: payload image IS img2) ...
+    g3 = LazyGrad(img2, "mask_losses", (img2.clone(), None, None, 2, None), lambda: grad)
+    assert g3.take("mask_losses", img2) is None              # ... a different storage is refused
