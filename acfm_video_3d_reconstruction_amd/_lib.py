@@ -44,6 +44,7 @@ SIGNATURES = {
     "acfm_deform_solve": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "acfm_deform_solve_backward": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp]),
     "acfm_deform_solve_info": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "acfm_deform_solve_info_offset": (_sz, [_i]),
     "acfm_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "acfm_stream_capture_id": (_i, [_vp, _vp]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,

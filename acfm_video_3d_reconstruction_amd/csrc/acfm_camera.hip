@@ -103,6 +103,10 @@ __device__ __forceinline__ void cam_backward(const float* __restrict__ e, const 
 // The same straight from the per-hypothesis embedding tables (mesh_net.py:436-444: one nn.Embedding(frames, 7) per
 // hypothesis): row r = g N + n reads tables[sel ? sel[r] : g][frames_idx[n]]; the backward adds into dense per-table
 // gradients (zeroed by the caller; float atomics: frames of a batch are distinct, so every cell gets one add).
+// A frame id outside [0, n_frames) or a table id outside [0, n_tables) -- nn.Embedding raises on those (main.py:551-570)
+// -- never becomes an address: the forward writes a NaN camera for that row (the loss of the step is then NaN, loudly,
+// without a host synchronisation inside a captured step), the backward skips it; ops.camera_pipeline_tables(check=True)
+// is the host-side check for data-loader batches.
 constexpr int CAM_MAX_TABLES = 32;
 struct CamTables {
   const float* t[CAM_MAX_TABLES];
@@ -110,12 +114,18 @@ struct CamTables {
 };
 __global__ void k_camera_fwd_tables(CamTables tb, const int64_t* __restrict__ frames_idx, const int64_t* __restrict__ sel,
                                     const int64_t* __restrict__ mirror, const float* __restrict__ transforms, int R, int N,
-                                    float decay, float* __restrict__ out) {
+                                    int n_tables, int n_frames, float decay, float* __restrict__ out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int n = r % N;
-  const int table = sel ? (int)sel[r] : r / N;
-  const float* src = tb.t[table] + (size_t)frames_idx[n] * 7;
+  const int64_t table = sel ? sel[r] : (int64_t)(r / N);
+  const int64_t frame = frames_idx[n];
+  if (table < 0 || table >= n_tables || frame < 0 || frame >= n_frames) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[(size_t)r * 7 + k] = __builtin_nanf("");
+    return;
+  }
+  const float* src = tb.t[table] + (size_t)frame * 7;
   float e[7], o[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) e[k] = src[k];
@@ -143,13 +153,16 @@ __global__ void k_camera_bwd(const float* __restrict__ emb, const int64_t* __res
 
 __global__ void k_camera_bwd_tables(CamTables tb, const int64_t* __restrict__ frames_idx, const int64_t* __restrict__ sel,
                                     const int64_t* __restrict__ mirror, const float* __restrict__ transforms,
-                                    const float* __restrict__ gout, int R, int N, float decay) {
+                                    const float* __restrict__ gout, int R, int N, int n_tables, int n_frames,
+                                    float decay) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int n = r % N;
-  const int table = sel ? (int)sel[r] : r / N;
+  const int64_t table = sel ? sel[r] : (int64_t)(r / N);
+  const int64_t frame = frames_idx[n];
+  if (table < 0 || table >= n_tables || frame < 0 || frame >= n_frames) return;   // (the forward wrote NaN for this row)
   if (!tb.g[table]) return;
-  const size_t row = (size_t)frames_idx[n] * 7;
+  const size_t row = (size_t)frame * 7;
   const float* src = tb.t[table] + row;
   float e[7], g[7], ge[7];
 #pragma unroll
@@ -250,7 +263,7 @@ int acfm_camera_pipeline_tables(const void* const* tables, int n_tables, int n_f
     if (i < n_tables && !tb.t[i]) return ACFM_E_BADARG;
   }
   hipLaunchKernelGGL(k_camera_fwd_tables, dim3((R + 127) / 128), dim3(128), 0, (hipStream_t)stream, tb, frames_idx,
-                     selected, mirror_flag, transforms, R, N, scale_lr_decay, cams);
+                     selected, mirror_flag, transforms, R, N, n_tables, n_frames, scale_lr_decay, cams);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
@@ -271,7 +284,7 @@ int acfm_camera_pipeline_tables_backward(const void* const* tables, int n_tables
     if (tb.g[i] && zero_async(tb.g[i], sizeof(float) * 7 * (size_t)n_frames, st) != ACFM_OK) return ACFM_E_LAUNCH;
   }
   hipLaunchKernelGGL(k_camera_bwd_tables, dim3((R + 127) / 128), dim3(128), 0, st, tb, frames_idx, selected,
-                     mirror_flag, transforms, grad_cams, R, N, scale_lr_decay);
+                     mirror_flag, transforms, grad_cams, R, N, n_tables, n_frames, scale_lr_decay);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }

@@ -463,10 +463,13 @@ __global__ __launch_bounds__(256) void k_chol_step(SolveWs s, int k) {
 // Critical path: the diagonal job of column c also carries the tile left of it, (c, c-1), so that after
 // L_{c-1,c-1}^-1 arrives it needs no second hand-off:  L_{c,c-1} = acc2 Linv^T,  acc -= L_{c,c-1} L_{c,c-1}^T,
 // factorise.  (The job of tile (c, c-1) computes the same tile for everybody else.)
-// Spins are bounded: on expiry the job raises CHOL_E_HANDOFF in info and carries on with what it has, so
-// the grid always drains.
+// Spins are bounded PER WAIT (2^19 polls of >= 0.1 us: a wave starved by time-slicing or by side-stream kernels on
+// its CU gets >= 50 ms for every single hand-off, not for the whole kernel): on expiry the job raises
+// ACFM_SOLVE_INFO_HANDOFF in info and carries on with what it has (sentinel NaNs then reach P), so the grid always
+// drains; the status word is how the host learns of it (acfm_deform_solve_info, or a non-blocking copy of the word at
+// acfm_deform_solve_info_offset).
 constexpr unsigned long long CHOL_SENTINEL = ~0ull;
-constexpr int CHOL_E_HANDOFF = 0x40000000;
+constexpr int CHOL_E_HANDOFF = ACFM_SOLVE_INFO_HANDOFF;
 constexpr int CHOL_SPIN_LIMIT = 1 << 19;
 
 __device__ __forceinline__ unsigned long long ld_word(const double* p) {
@@ -487,8 +490,9 @@ __device__ __forceinline__ bool ld_operand(const double* tile_row, double (&v)[8
   }
   return bad;
 }
-// wave-uniform wait for one word of a tile; false on expiry
+// wave-uniform wait for one word of a tile; false on expiry (a fresh budget for every wait)
 __device__ __forceinline__ bool gate(const double* word, int& budget) {
+  budget = CHOL_SPIN_LIMIT;
   while (ld_word(word) == CHOL_SENTINEL) {
     if (--budget < 0) return false;
     __builtin_amdgcn_s_sleep(4);
@@ -644,6 +648,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(SolveWs s, int Kh, float* __
     if (jd >= 0) {
       double inv[8];
       const double* rowI = s.Linv + (size_t)jd * NB * NB + (size_t)(16 * qj + x) * NB + y;
+      budget = CHOL_SPIN_LIMIT;
       for (;;) {
         const bool bad = ld_operand(rowI, inv);
         if (!__any(bad) || expired) break;
@@ -912,6 +917,12 @@ int acfm_debug_solve_stamps(const void* ws, int V, long long* out_host, int n) {
   return hipMemcpy(out_host, s.Z, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? ACFM_OK : ACFM_E_LAUNCH;
 }
 #endif
+
+size_t acfm_deform_solve_info_offset(int V) {
+  if (V <= 0) return 0;
+  SolveWs s = carve_solve(nullptr, V);
+  return (size_t)((char*)s.info - (char*)nullptr);
+}
 
 int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_host, void* stream) {
   if (!ws || !info_host || V <= 0) return ACFM_E_BADARG;

@@ -16,6 +16,8 @@ The optimiser must keep its state on the device (torch.optim.Adam(..., capturabl
 """
 import torch
 
+from . import ops
+
 
 def _flat_tensors(x):
     if torch.is_tensor(x):
@@ -85,5 +87,5 @@ class GraphedStep:
             for k, v in inputs.items():
                 if torch.is_tensor(v):
                     self.static[k].copy_(v)
-        self.graph.replay()
+        ops.graph_replay(self.graph)      # (+ invalidate_setups(): the replay rewrites tensors without version bumps)
         return self.loss

@@ -243,7 +243,12 @@ class MultiframeStep(nn.Module):
         tl, tw, tg, ta = [mask_loss, edt, bdt], [o.mask_loss_wt, o.boundaries_reg_wt * o.edt_reg_wt,
                                                   o.boundaries_reg_wt * o.bdt_reg_wt], [-1, 0, 0], \
             [0.0, o.edt_reg_wt, o.bdt_reg_wt]
-        if of_term.numel() == G * N:
+        if o.of_loss_wt > 0 and "optical_flows" in batch:     # (else _flow_term returned main.py:688's zeros(1) placeholder)
+            if of_term.numel() != G * N:
+                # main.py:684-686 lays the per-clip loss out with repeat(1, T): G*B*(T-1)*T elements, = G*N only for the
+                # T = 2 clips ACFM trains on; the reference's `total_loss += of_loss_wt * of_loss` fails to broadcast otherwise
+                raise ValueError("optical-flow term has %d elements for %d hypotheses x %d frames (num_frames must be 2, "
+                                 "multiframe/main.py:684-686)" % (of_term.numel(), G, N))
             tl.append(of_term); tw.append(o.of_loss_wt); tg.append(-1); ta.append(0.0)
         if o.kp_loss_wt > 0 and self.vert2kp is not None:
             kp_v = torch.matmul(torch.softmax(self.vert2kp, dim=1), pred_v)

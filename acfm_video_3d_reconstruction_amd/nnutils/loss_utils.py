@@ -20,7 +20,8 @@ def _is_mask_batch(predict, target):
 
 def iou(predict, target, eps=1e-6, reduce=True):
     """loss_utils.py:18-28."""
-    out = ops.mask_losses(predict.reshape(predict.shape[0], -1), target.reshape(target.shape[0], -1))
+    # (the prediction goes in as it is, not as a [N, H W] view: see l1_loss)
+    out = ops.mask_losses(predict, target.reshape(target.shape[0], -1))
     r = out[:, 1] / (out[:, 2] + eps)
     if reduce:
         return r.sum() / r.nelement()
@@ -34,7 +35,9 @@ def iou_loss(predict, target, reduce=True):
 
 def l1_loss(predict, target, reduce=True):
     """loss_utils.py:72-77."""
-    out = ops.mask_losses(predict.reshape(predict.shape[0], -1), target.reshape(target.shape[0], -1))
+    # the rendered mask goes in as it is: its gradient then reaches the render's backward unformed (ops.LazyGrad) -- and
+    # summed, still unformed, with edt_loss's on the same mask (main.py:644, 716) -- and that kernel forms it per pixel
+    out = ops.mask_losses(predict, target.reshape(target.shape[0], -1))
     if reduce:
         return out[:, 0].mean()  # equal element counts per row: mean of row means == global mean
     return out[:, 0]
@@ -47,7 +50,7 @@ def edt_loss(mask_rendered, edt, reduce=True):
         # the reference broadcasts mask[:, None] over C channels and averages everything
         err = (edt * mask_rendered[:, None]).reshape(bsize, -1).mean(-1)
         return err.mean() if reduce else err
-    out = ops.mask_losses(mask_rendered.reshape(bsize, -1), None, edt.reshape(bsize, -1))
+    out = ops.mask_losses(mask_rendered, None, edt.reshape(edt.shape[0], -1))
     return out[:, 3].mean() if reduce else out[:, 3]
 
 
@@ -242,11 +245,32 @@ def kp_l2_loss(kp_pred, kp_gt, reduction='mean'):
 
 
 class PerceptualTextureLoss_v2(object):
-    """loss_utils.py:359-383 wraps the third-party `lpips` AlexNet; out of scope here."""
+    """loss_utils.py:359-383: LPIPS (AlexNet features, spatial map) between the masked rendered texture and the masked
+    image, times the ground-truth mask, mean over the pixels.  The network is the third-party `lpips` package, kept as
+    the torch module it is and imported when the loss is constructed: without the package the
+    constructor raises an ImportError naming it, with it predictor.py:103-108 and main.py:333-335 construct and call
+    this class unchanged.  The module lives on the GPU the process uses (the reference: `.cuda()` + nn.DataParallel)."""
 
     def __init__(self, net='alex', lpips_f=False):
-        raise NotImplementedError("LPIPS is a third-party network (lpips package) and is not part of "
-                                  "the MI355X hot path; plug the reference's module in unchanged")
+        try:
+            import lpips
+        except ImportError as exc:
+            raise ImportError("PerceptualTextureLoss_v2 needs the third-party `lpips` package (pip install lpips; the "
+                              "reference pins none, docs/install.md): it is the AlexNet perceptual metric, not part of "
+                              "the MI355X hot path -- every other loss of loss_utils works without it") from exc
+        fn = lpips.LPIPS(net=net, lpips=lpips_f, spatial=True)
+        if torch.cuda.is_available():
+            fn = fn.cuda()
+        self.loss_fn_alex = nn.DataParallel(fn)
+
+    def __call__(self, img_pred, img_gt, mask_pred, mask_gt, reduce=True):
+        """img_pred, img_gt [B,3,H,W]; mask_pred (unused, as in the reference), mask_gt [B,H,W] -> scalar or [B]."""
+        mask_gt = mask_gt.unsqueeze(1)
+        pred = 2 * (img_pred * mask_gt) - 1
+        target = 2 * (img_gt * mask_gt) - 1
+        dist = self.loss_fn_alex(pred, target) * mask_gt
+        dist = dist.mean(-2).mean(-1).squeeze(-1)          # [B,1,H,W] -> [B], rows first as in the reference
+        return dist.mean() if reduce else dist
 
 
 class TexCycle(nn.Module):

@@ -4,6 +4,7 @@ torch is used here for device memory, streams and autograd bookkeeping only; eve
 is one or more stream-ordered calls into libacfm_hip.so."""
 import ctypes
 import math
+import threading
 
 import torch
 
@@ -48,11 +49,12 @@ def expand_faces(faces, N):
         return faces
     key = (faces.data_ptr(), faces.storage_offset(), faces.stride(), faces._version, tuple(faces.shape),
            str(faces.dtype), str(faces.device))
-    hit = _FACES.get(key)
-    if hit is None:
-        if len(_FACES) > 8:
-            _FACES.clear()
-        hit = _FACES[key] = (faces, faces.to(torch.int64).contiguous())
+    with _LOCK:
+        hit = _FACES.get(key)
+        if hit is None:
+            if len(_FACES) > 8:
+                _FACES.clear()
+            hit = _FACES[key] = (faces, faces.to(torch.int64).contiguous())
     return hit[1]
 
 
@@ -72,43 +74,42 @@ def _workspace(N, V, F, H, device):
 #   * same HIP stream (the texture render is ordered behind the silhouette render that filled ws);
 #   * same capture: both calls are eager, or both are recorded into the SAME hipGraph capture (id from
 #     hipStreamGetCaptureInfo) -- a workspace never crosses a graph boundary;
-#   * same replay epoch: any hipGraph replay (torch.cuda.CUDAGraph.replay is wrapped below) may have
-#     rewritten static input buffers without touching their version counters, so it ends every sharing.
-# Writes that bypass all of these (`t.data` in-place ops, foreign kernels on raw pointers) are the
-# caller's to announce with invalidate_setups(); share_setup(False) turns the take-over off.
+#   * same epoch: invalidate_setups() ends every sharing.  A hipGraph REPLAY rewrites the tensors its capture wrote
+#     without touching their version counters, so whoever replays a graph and then hands such tensors to the renderers
+#     eagerly announces it with invalidate_setups() (graphed.GraphedStep.replay and bench.py do; torch itself is not
+#     edited -- round 2 wrapped torch.cuda.CUDAGraph.replay process-wide for this).  Writes that bypass the version
+#     counters in other ways (`t.data` in-place ops, foreign kernels on raw pointers) are the caller's to announce
+#     the same way; share_setup(False) turns the take-over off.
+# The caches below (_SETUP, _COVER, _FACES) are shared by the threads nn.DataParallel runs its replicas on
+# (main.py:183-193): every read-modify-write of them happens under _LOCK.
 _SETUP = {}
 _EPOCH = [0]
 _SHARE = [True]
+_LOCK = threading.RLock()
 
 
 def invalidate_setups():
-    """Forget every cached face setup (call after writing to verts / cams / faces behind torch's back)."""
-    _EPOCH[0] += 1
-    _SETUP.clear()
+    """Forget every cached face setup: call after writing to verts / cams / faces behind torch's back, and after a
+    hipGraph replay whose outputs are then rendered eagerly (see above)."""
+    with _LOCK:
+        _EPOCH[0] += 1
+        _SETUP.clear()
 
 
 def share_setup(on):
     """Enable / disable the silhouette -> texture workspace take-over (default on).  Returns the old value."""
-    old, _SHARE[0] = _SHARE[0], bool(on)
-    if not on:
-        _SETUP.clear()
+    with _LOCK:
+        old, _SHARE[0] = _SHARE[0], bool(on)
+        if not on:
+            _SETUP.clear()
     return old
 
 
-def _wrap_graph_replay():
-    cls = getattr(torch.cuda, "CUDAGraph", None)
-    if cls is None or getattr(cls.replay, "_acfm_wrapped", False):
-        return
-    inner = cls.replay
-
-    def replay(self):
-        _EPOCH[0] += 1          # static buffers may change under unchanged version counters
-        return inner(self)
-    replay._acfm_wrapped = True
-    cls.replay = replay
-
-
-_wrap_graph_replay()
+def graph_replay(graph):
+    """graph.replay() + invalidate_setups(): the replay of a torch.cuda.CUDAGraph whose tensors are also handed to
+    the renderers outside the graph."""
+    invalidate_setups()
+    return graph.replay()
 
 
 def _capture_id(device):
@@ -137,25 +138,35 @@ _COVER = {}
 def _cover_tuning(device, tune):
     """Tuning for a silhouette render on `device`: `tune` with the cover flag decided."""
     forced = getattr(tune, "record_cover", None) if tune is not None else None
-    st = _COVER.setdefault(device, {"on": False, "pending": False})
     if forced is not None:
         return _lib.with_cover(tune, bool(forced))
-    if st["pending"]:          # the last plane was never read: stop recording
-        st["on"] = False
-    st["pending"] = st["on"]
-    return _lib.with_cover(tune, st["on"])
+    with _LOCK:
+        st = _COVER.setdefault(device, {"on": False, "pending": False})
+        if st["pending"]:          # the last plane was never read: stop recording
+            st["on"] = False
+        st["pending"] = on = st["on"]
+    return _lib.with_cover(tune, on)
 
 
 def _cover_taken(device, tune):
     """A texture render took a silhouette render's workspace over: -> the ws_ready value for the C ABI."""
-    st = _COVER.setdefault(device, {"on": False, "pending": False})
-    st["on"], st["pending"] = True, False
+    with _LOCK:
+        st = _COVER.setdefault(device, {"on": False, "pending": False})
+        st["on"], st["pending"] = True, False
     return 2 if (tune is not None and tune.flags & 4) else 1
+
+
+def _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune):
+    if _SHARE[0]:
+        ent = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
+        with _LOCK:
+            _SETUP[v.device] = ent
 
 
 def _shared_setup(v, c, f, H, offset_z):
     """-> (ws, nbytes, blur, tuning) of a silhouette render of exactly these inputs, or None."""
-    ent = _SETUP.get(v.device) if _SHARE[0] else None
+    with _LOCK:
+        ent = _SETUP.get(v.device) if _SHARE[0] else None
     if ent is not None and ent[0] == _setup_key(v, c, f, H, offset_z):
         return ent[1], ent[2], ent[3], ent[5]
     return None
@@ -268,6 +279,47 @@ def deform_apply(mean_v, P, delta):
     return _DeformApply.apply(mean_v, P, delta)
 
 
+SOLVE_INFO_HANDOFF = 0x40000000   # ACFM_SOLVE_INFO_HANDOFF (include/acfm_hip.h)
+
+
+def decode_solve_info(info):
+    """Status word of acfm_deform_solve -> None (ok) or the message of the error it stands for."""
+    info = int(info)
+    if info == 0:
+        return None
+    if info & SOLVE_INFO_HANDOFF:
+        return ("deform_solve: a hand-off wait of the single-launch factorisation expired (a wave of k_chol_tiles was "
+                "starved for > 50 ms, e.g. by time-slicing or side-stream kernels on its CU): P holds NaNs -- run the "
+                "solve again")
+    return ("deform_solve: L^T L + A^T A is not positive definite (pivot tile starting at row %d)"
+            % ((info & (SOLVE_INFO_HANDOFF - 1)) - 1))
+
+
+# Status words of the solves launched with check=False (DeformSolver's per-step factorisations), copied to pinned host
+# memory without blocking: (event, pinned int32).  The next deform_solve / solve_status() call reads those whose copy
+# has completed and raises for a failed one -- a step late, but never silently and never with a synchronisation.
+_SOLVE_PENDING = []
+
+
+def solve_status(wait=False):
+    """Raise RuntimeError for any earlier deform_solve(check=False) whose status word has arrived and reports a failure
+    (a non-positive pivot, an expired hand-off).  wait=True: first wait for the outstanding ones (synchronises)."""
+    with _LOCK:
+        pending, _SOLVE_PENDING[:] = list(_SOLVE_PENDING), []
+    msg, keep = None, []
+    for ev, host in pending:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            msg = msg or decode_solve_info(host.item())
+        else:
+            keep.append((ev, host))
+    with _LOCK:
+        _SOLVE_PENDING[:0] = keep
+    if msg:
+        raise RuntimeError(msg + " [reported by an earlier deform_solve(check=False)]")
+
+
 class _DeformSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, L, lbs, check):
@@ -278,6 +330,9 @@ class _DeformSolve(torch.autograd.Function):
             raise ValueError("L must be [V,V] = [%d,%d], got %s" % (V, V, tuple(l.shape)))
         if Kh > 32:
             raise ValueError("at most 32 handles (got %d)" % Kh)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            solve_status()
         lib = _lib.lib()
         nbytes = lib.acfm_deform_solve_workspace_bytes(V, Kh)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
@@ -287,13 +342,21 @@ class _DeformSolve(torch.autograd.Function):
             _lib.check(lib.acfm_deform_solve(_lib.ptr(l), _lib.ptr(b), V, Kh, _lib.ptr(P), _lib.ptr(ws), nbytes, st),
                        "acfm_deform_solve")
             if check:
-                import ctypes
                 info = ctypes.c_int(0)
                 _lib.check(lib.acfm_deform_solve_info(_lib.ptr(ws), nbytes, V, ctypes.byref(info), st),
                            "acfm_deform_solve_info")
-                if info.value:
-                    raise RuntimeError("deform_solve: L^T L + A^T A is not positive definite "
-                                       "(pivot tile starting at row %d)" % (info.value - 1))
+                msg = decode_solve_info(info.value)
+                if msg:
+                    raise RuntimeError(msg)
+            elif not capturing:
+                off = lib.acfm_deform_solve_info_offset(V)
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(b.device))
+                with _LOCK:
+                    _SOLVE_PENDING.append((ev, host))
+                    del _SOLVE_PENDING[:-8]
         ctx.ws, ctx.dims = ws, (V, Kh)
         return P
 
@@ -315,7 +378,9 @@ def deform_solve(L, lbs_logits, check=False):
     """P [V,K_h] = (L^T L + A^T A)^-1 A^T with A = softmax(lbs_logits, dim 0)^T: the reference's
     per-frame Cholesky solve (multiframe/main.py:586-609) collapsed to one fp64 factorisation per
     step.  L [V,V] dense Laplacian (no gradient), lbs_logits [V,K_h] (gradient supported).
-    check=True synchronises and raises if the matrix is not positive definite."""
+    check=True synchronises and raises if the matrix is not positive definite or a hand-off of the single-launch
+    factorisation timed out (decode_solve_info); check=False (the per-step path) copies the status word to the host
+    without blocking and the NEXT deform_solve / solve_status() call raises for it."""
     return _DeformSolve.apply(L, lbs_logits, bool(check))
 
 
@@ -408,12 +473,23 @@ class _CameraPipelineTables(torch.autograd.Function):
 
 
 def camera_pipeline_tables(tables, frames_idx, mirror_flag, transforms, scale_lr_decay=1.0, num_guesses=None,
-                           selected=None):
+                           selected=None, check=False):
     """Cameras [G*N,7] of all hypotheses straight from the per-hypothesis embedding tables ([frames,7] each,
     mesh_net.py:436-444): the look-ups, the stack / top-k gather (main.py:551-570) and the decode / mirror / transform
     chain (:572-584) in one kernel each way.  Row g*N + n reads tables[selected[g, n] if given else g][frames_idx[n]];
-    the backward returns dense [frames,7] gradients like nn.Embedding's."""
+    the backward returns dense [frames,7] gradients like nn.Embedding's.
+    A frames_idx outside [0, frames) or a `selected` outside [0, len(tables)) -- where nn.Embedding raises -- gives that
+    row a NaN camera and no gradient (never an out-of-bounds access); check=True validates both on the host first
+    (one synchronisation: for data-loader batches, not inside a captured step) and raises IndexError."""
     G = len(tables) if num_guesses is None else int(num_guesses)
+    if check:
+        nf = tables[0].shape[0]
+        lo, hi = int(frames_idx.min()), int(frames_idx.max())
+        if lo < 0 or hi >= nf:
+            raise IndexError("camera_pipeline_tables: frames_idx in [%d, %d] outside the %d rows of the embedding tables"
+                             % (lo, hi, nf))
+        if selected is not None and (int(selected.min()) < 0 or int(selected.max()) >= len(tables)):
+            raise IndexError("camera_pipeline_tables: selected hypothesis outside the %d tables" % len(tables))
     return _CameraPipelineTables.apply(frames_idx, selected, mirror_flag, transforms, scale_lr_decay, G, *tables)
 
 
@@ -534,18 +610,20 @@ def correlation(f1, f2, max_displacement):
 class LazyPixToFace(torch.Tensor):
     """`pix_to_face [N,H,W,K]` int64 as the reference's renderer returns it, with the K-1 planes nobody in the training
     path reads produced on first use.  The render writes the nearest-face plane (all that loss_utils.py:214 `[..., 0]`
-    and :431 `[..., :1]` read: 8 bytes per pixel instead of 8 K); `p[..., 0]` and `p[..., :1]` are views of it; ANY other
+    and :431 `[..., :1]` read: 8 bytes per pixel instead of 8 K); `p[..., 0]` and `p[..., :1]` are views of it; splitting
+    along the batch dimension (`p[a:b]`, `p[n]`, `chunk` / `split` on dim 0 -- what nn.DataParallel's scatter does to
+    every tensor argument, main.py:326, 718, also on one device) gives lazy tensors over the parts; ANY other
     operation (indexing another slot, .cpu(), comparisons, printing ...) first renders the full tensor -- the same
     kernel once more with all K slots stored, from the very tensors of the original call -- and then behaves like the
-    plain tensor.  If those inputs changed meanwhile (in-place write, or a hipGraph replay that may have rewritten
-    static buffers) it raises instead of returning ids of other geometry: NeuralRenderer(pix_to_face_slots=K) stores
-    all K slots at render time."""
+    plain tensor.  If those inputs changed meanwhile (in-place write, invalidate_setups()) it raises instead of
+    returning ids of other geometry: NeuralRenderer(pix_to_face_slots=K) stores all K slots at render time."""
 
     @staticmethod
-    def __new__(cls, plane0, K, make_full):
-        N, H, W, _ = plane0.shape
-        r = torch.Tensor._make_wrapper_subclass(cls, (N, H, W, int(K)), dtype=plane0.dtype, device=plane0.device)
+    def __new__(cls, plane0, K, make_full, vis=None):
+        shape = tuple(plane0.shape[:-1]) + (int(K),)
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=plane0.dtype, device=plane0.device)
         r._plane0, r._make_full, r._full = plane0, make_full, None
+        r._acfm_vis = vis
         return r
 
     @property
@@ -561,19 +639,57 @@ class LazyPixToFace(torch.Tensor):
     def __repr__(self):
         return "LazyPixToFace(shape=%s, materialized=%s)" % (tuple(self.shape), self.is_materialized)
 
+    def __deepcopy__(self, memo):
+        return self.materialize().clone()
+
+    def _rows(self, start, end, squeeze=False):
+        """Lazy tensor over meshes start..end-1 (squeeze: the single mesh `start`, batch dimension dropped)."""
+        parent = self
+        pl = self._plane0[start] if squeeze else self._plane0[start:end]
+        vis = self._acfm_vis
+        if vis is not None:
+            vis = None if squeeze else vis[start:end]
+        return LazyPixToFace(pl, self.shape[-1], (lambda: parent.materialize()[start] if squeeze
+                                                  else parent.materialize()[start:end]), vis)
+
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         a0 = args[0] if args else None
         if isinstance(a0, LazyPixToFace) and a0._full is None:
             nd = a0.dim()
-            if func is torch.ops.aten.select.int and args[1] in (nd - 1, -1) and args[2] == 0:
+            aten = torch.ops.aten
+            dim = args[1] if len(args) > 1 and isinstance(args[1], int) else None
+            last = dim in (nd - 1, -1) and nd > 1
+            first = dim in (0, -nd) and nd == 4
+            if func is aten.select.int and last and args[2] == 0:
                 return a0._plane0.select(nd - 1, 0)
-            if func is torch.ops.aten.slice.Tensor and len(args) >= 4 and args[1] in (nd - 1, -1) and \
-                    args[2] in (0, None) and args[3] == 1 and (len(args) < 5 or args[4] == 1):
+            if func is aten.slice.Tensor and last and len(args) >= 4 and args[2] in (0, None) and args[3] == 1 and \
+                    (len(args) < 5 or args[4] == 1):
                 return a0._plane0
-            if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default):
+            if func in (aten.detach.default, aten.alias.default):
                 return a0
+            N = a0.shape[0]
+            if func is aten.select.int and first:
+                i = args[2] + N if args[2] < 0 else args[2]
+                if 0 <= i < N:
+                    return a0._rows(i, i + 1, squeeze=True)
+            if func is aten.slice.Tensor and (first or (len(args) == 1 and nd == 4)) and (len(args) < 5 or args[4] == 1):
+                lo = args[2] if len(args) > 2 and args[2] is not None else 0
+                hi = args[3] if len(args) > 3 and args[3] is not None else N
+                lo = max(0, lo + N if lo < 0 else lo)
+                hi = min(N, hi + N if hi < 0 else hi)
+                if lo < hi:
+                    return a0._rows(lo, hi)
+            if func is aten.split.Tensor and (len(args) < 3 or args[2] in (0, -nd)) and nd == 4 and args[1] > 0:
+                return [a0._rows(lo, min(N, lo + args[1])) for lo in range(0, N, args[1])]
+            if func is aten.split_with_sizes.default and (len(args) < 3 or args[2] in (0, -nd)) and nd == 4 and \
+                    sum(args[1]) == N and all(x > 0 for x in args[1]):
+                out, lo = [], 0
+                for x in args[1]:
+                    out.append(a0._rows(lo, lo + x))
+                    lo += x
+                return out
         from torch.utils._pytree import tree_map
         unwrap = lambda x: x.materialize() if isinstance(x, LazyPixToFace) else x
         return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
@@ -583,12 +699,20 @@ def _lazy_pix_to_face(plane0, vis, v, f, c, H, K, blur, sigma, offset_z):
     """Wraps the nearest-face plane of a silhouette render (see LazyPixToFace)."""
     versions = (v._version, f._version, c._version, _EPOCH[0])
     tune = _lib.tuning()[1]
+    born_in = _capture_id(v.device)
 
     def make_full():
         if (v._version, f._version, c._version, _EPOCH[0]) != versions:
             raise RuntimeError("pix_to_face: slots beyond [..., 0] are rendered on first use, but the vertices / faces / "
-                               "cameras of that render have been modified since (in-place write or a hipGraph replay); "
+                               "cameras of that render have been modified since (in-place write, or a hipGraph replay "
+                               "announced with invalidate_setups()); "
                                "use NeuralRenderer(pix_to_face_slots=faces_per_pixel) to store every slot at render time")
+        if _capture_id(v.device) != born_in:
+            # made while a hipGraph was being captured: its inputs are the capture's buffers, which hold nothing until a
+            # replay and whatever the last replay left afterwards -- there is no "the render's inputs" to re-render from
+            raise RuntimeError("pix_to_face: this tensor was rendered inside a hipGraph capture; its slots beyond [..., 0] "
+                               "can only be formed inside that same capture.  Use NeuralRenderer(pix_to_face_slots="
+                               "faces_per_pixel) in captured steps that read them")
         N, V, _ = v.shape
         F = f.shape[1]
         mask = torch.empty((N, H, H), dtype=torch.float32, device=v.device)
@@ -603,9 +727,7 @@ def _lazy_pix_to_face(plane0, vis, v, f, c, H, K, blur, sigma, offset_z):
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_forward")
         return full
 
-    p = LazyPixToFace(plane0, K, make_full)
-    p._acfm_vis = vis
-    return p
+    return LazyPixToFace(plane0, K, make_full, vis)
 
 
 # The reference computes its losses on the rendered images with separate operators (main.py:644-662, 716-717), so the
@@ -614,16 +736,26 @@ def _lazy_pix_to_face(plane0, vis, v, f, c, H, K, blur, sigma, offset_z):
 # gradient per pixel themselves (acfm_sil_loss_backward, acfm_tex_mse_backward_faces: the opt-in fused operators).
 # LazyGrad lets the drop-in operators use them too: the loss operator's backward hands autograd a tensor of the right
 # shape that merely REMEMBERS how the gradient is defined (the operator's inputs and its upstream gradient); the render's
-# backward recognises it -- same image, untouched -- and calls the fused kernel; ANY other use of it (a hook, a second
-# consumer whose gradient autograd adds to it, torch.autograd.grad with respect to the image itself) forms the
-# gradient with the loss operator's own backward kernel first and then behaves like the plain tensor.
+# backward recognises it -- same image, untouched -- and calls the fused kernel.  Two things autograd does to such a
+# gradient on the reference's own call sequence stay lazy: shape-only views (l1_loss / iou hand the operator
+# `mask.view(N, -1)` / `mask[:, None]`, loss_utils.py:18-32, 72-77: the view's backward reshapes the gradient) and the
+# SUM of the gradients of two silhouette-loss operators on the same mask (l1_loss and edt_loss, main.py:644 and :716:
+# the sum is the gradient of one operator with both references and the two upstream gradients added).  ANY other use
+# (a hook, another consumer's gradient added, torch.autograd.grad with respect to the image itself) forms the gradient
+# with the loss operator's own backward kernel first and then behaves like the plain tensor.
 LAZY_GRADS = [True]
+
+
+def _same_tensor(a, b):
+    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                      and a._version == b._version and a.dtype == b.dtype)
 
 
 class LazyGrad(torch.Tensor):
     @staticmethod
-    def __new__(cls, like, tag, payload, make_full):
-        r = torch.Tensor._make_wrapper_subclass(cls, tuple(like.shape), dtype=like.dtype, device=like.device)
+    def __new__(cls, like, tag, payload, make_full, shape=None):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(like.shape) if shape is None else tuple(shape),
+                                                dtype=like.dtype, device=like.device)
         r._tag, r._payload, r._make_full, r._full = tag, payload, make_full, None
         return r
 
@@ -633,19 +765,54 @@ class LazyGrad(torch.Tensor):
 
     def materialize(self):
         if self._full is None:
-            self._full = self._make_full()
+            self._full = self._make_full().reshape(self.shape)
             self._make_full = self._payload = None
         return self._full
 
     def take(self, tag, image):
         """The operator inputs behind this gradient if it is still unformed, of kind `tag`, and a gradient with
-        respect to exactly `image` (same storage, shape and version); else None."""
+        respect to exactly `image` (same storage, element count and version); else None."""
         if self._full is not None or self._tag != tag:
             return None
         img = self._payload[0]
-        if img.data_ptr() != image.data_ptr() or img.shape != image.shape or img._version != image._version:
+        if img.data_ptr() != image.data_ptr() or img.numel() != image.numel() or self.numel() != image.numel() or \
+                img._version != image._version:
             return None
         return self._payload
+
+    def _reshaped(self, shape):
+        parent = self
+        return LazyGrad(self, self._tag, self._payload, lambda: parent.materialize(), shape=shape)
+
+    def _merged(self, other):
+        """self + other for two unformed silhouette-loss gradients of the same mask, itself unformed; else None."""
+        if self._full is not None or other._full is not None or self._tag != "mask_losses" or other._tag != "mask_losses" \
+                or self.shape != other.shape:
+            return None
+        m1, g1, e1, rb1, go1 = self._payload
+        m2, g2, e2, rb2, go2 = other._payload
+        if not _same_tensor(m1, m2):
+            return None
+        if (g1 is not None and g2 is not None and not _same_tensor(g1, g2)) or \
+                (e1 is not None and e2 is not None and not _same_tensor(e1, e2)):
+            return None
+        refs = [r for r in (g1, g2, e1, e2) if r is not None]
+        if any(r.shape[0] != refs[0].shape[0] for r in refs):
+            return None
+        # a term whose reference an operator did not have contributes nothing to that operator's gradient
+        # (acfm_mask_losses_backward skips it): mask its columns before the two upstream gradients are added
+        def cols(go, g, e):
+            if g is not None and e is not None:
+                return go
+            return go * _lib.const((1.0, 1.0, 1.0, 0.0) if e is None else (0.0, 0.0, 0.0, 1.0), go.device)
+        go = cols(go1, g1, e1) + cols(go2, g2, e2)
+        g, e = (g1 if g1 is not None else g2), (e1 if e1 is not None else e2)
+        rb = refs[0].shape[0] if refs else m1.shape[0]
+        a, b = self, other
+
+        def make():
+            return a.materialize() + b.materialize()
+        return LazyGrad(self, "mask_losses", (m1, g, e, rb, go), make)
 
     def __repr__(self):
         return "LazyGrad(%s, shape=%s, materialized=%s)" % (self._tag, tuple(self.shape), self.is_materialized)
@@ -653,9 +820,36 @@ class LazyGrad(torch.Tensor):
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default) and type(args[0]) is LazyGrad \
-                and args[0]._full is None:
-            return args[0]
+        aten = torch.ops.aten
+        a0 = args[0] if args else None
+        if type(a0) is LazyGrad and a0._full is None:
+            if func in (aten.detach.default, aten.alias.default):
+                return a0
+            if func in (aten.view.default, aten.reshape.default, aten._unsafe_view.default):
+                shape = list(args[1])
+                if -1 in shape:
+                    known = 1
+                    for x in shape:
+                        known *= x if x != -1 else 1
+                    shape[shape.index(-1)] = a0.numel() // max(known, 1)
+                n = 1
+                for x in shape:
+                    n *= x
+                if n == a0.numel():
+                    return a0._reshaped(shape)
+            if func is aten.squeeze.dim and a0.shape[args[1]] == 1:
+                shape = list(a0.shape)
+                del shape[args[1]]
+                return a0._reshaped(shape)
+            if func is aten.unsqueeze.default:
+                shape = list(a0.shape)
+                shape.insert(args[1] if args[1] >= 0 else args[1] + a0.dim() + 1, 1)
+                return a0._reshaped(shape)
+            if func is aten.add.Tensor and len(args) == 2 and type(args[1]) is LazyGrad and \
+                    kwargs.get("alpha", 1) == 1:
+                m = a0._merged(args[1])
+                if m is not None:
+                    return m
         from torch.utils._pytree import tree_map
         unwrap = lambda x: x.materialize() if type(x) is LazyGrad else x
         return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
@@ -686,8 +880,7 @@ class _SilRender(torch.autograd.Function):
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
                 float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
                 _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)), "acfm_sil_forward")
-        if _SHARE[0]:
-            _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
+        _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune)
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
         ctx.ws = (ws, nb, tune)  # face records + tile schedule: reused by backward (no second setup)
@@ -778,8 +971,7 @@ class _SilRenderLosses(torch.autograd.Function):
                 float(blur), float(sigma), float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth),
                 _lib.ptr(vis), _lib.ptr(losses), _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)),
                 "acfm_sil_loss_forward")
-        if _SHARE[0]:
-            _SETUP[v.device] = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
+        _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune)
         ctx.save_for_backward(v, f, c, mask, kth, g, e)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z), RB)
         ctx.ws = (ws, nb, tune)
@@ -884,27 +1076,23 @@ class _TexRender(torch.autograd.Function):
                 float(gamma), float(offset_z), _lib.ptr(imgs), _lib.ptr(sil), _lib.ptr(p2f),
                 _lib.ptr(tidx), _lib.ptr(ws), nb, ws_ready, float(ws_blur), NA,
                 _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_tex_forward")
-        ctx.save_for_backward(tidx)
+        ctx.save_for_backward(tidx, imgs)   # (imgs: to recognise a LazyGrad of this very image, at this version, in the backward)
         ctx.cfg = (N, F, H, R, NA, V)
         ctx.adt = atlas.dtype
         ctx.tune, ctx.f16 = tune, f16
         ctx.ws = (ws, nb, float(ws_blur))   # face boxes: the gather form of the atlas gradient walks them
-        ctx.imgs_ref = (imgs.data_ptr(), imgs.shape)   # (to recognise a LazyGrad of this very image in the backward)
         ctx.mark_non_differentiable(sil, p2f)
         ctx.set_materialize_grads(False)
         return imgs, sil, p2f
 
     @staticmethod
     def backward(ctx, gimgs, _gs, _gp):
-        (tidx,) = ctx.saved_tensors
+        tidx, imgs = ctx.saved_tensors
         N, F, H, R, NA, V = ctx.cfg
         ga = None
         pay = None
-        if ctx.needs_input_grad[3] and type(gimgs) is LazyGrad and TEX_BWD_GATHER and R <= 8 and not ctx.f16 and \
-                gimgs._full is None and gimgs._tag == "tex_mse":
-            t0 = gimgs._payload[0]
-            if (t0.data_ptr(), t0.shape) == ctx.imgs_ref:
-                pay = gimgs._payload
+        if ctx.needs_input_grad[3] and type(gimgs) is LazyGrad and TEX_BWD_GATHER and R <= 8 and not ctx.f16:
+            pay = gimgs.take("tex_mse", imgs)
         if pay is not None:      # the texture MSE's gradient, still unformed: the atlas-gradient kernel forms it per pixel
             t0, ri, rm, rb, go = pay
             ga = torch.empty((NA, F, R, R, 3), dtype=torch.float32, device=t0.device)
@@ -1093,7 +1281,7 @@ class _MaskLosses(torch.autograd.Function):
                                                                 _lib.cur_stream(m.device)),
                            "acfm_mask_losses_backward")
             return gm
-        if LAZY_GRADS[0] and m.dim() == 3 and m.shape[1] == m.shape[2]:
+        if LAZY_GRADS[0] and m.dim() >= 2:
             return LazyGrad(m, "mask_losses", (m, g, e, rb, go), make), None, None
         return make(), None, None
 

@@ -8,6 +8,7 @@ P = M^-1 A^T is factorised once (deform.DeformSolver) and every iteration applie
 v = v_mean + P (delta).  Same losses, same weights, same optimiser (Adam, lr 5e-3)."""
 import torch
 
+from . import ops
 from .nnutils import loss_utils
 
 
@@ -104,6 +105,7 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
             iteration()                      # recorded, not executed
         for _ in range(num_optim_iter - n_eager):
             graph.replay()
+        ops.invalidate_setups()              # the replays rewrote the loop's tensors without version bumps
     else:
         for _ in range(num_optim_iter):
             iteration()

@@ -199,8 +199,10 @@ class SharedShapeExchange:
         o = gP.numel()
         G = flat[:o].view_as(gP)
         if s.lbs.requires_grad:
-            s.lbs.grad = None
-            self._P.backward(G)                                       # d lbs = solve_backward(G): identical on every rank
+            direct, s.lbs.grad = s.lbs.grad, None                     # a direct term on lbs (a regulariser: replicated,
+            self._P.backward(G)                                       # identical on every rank) is kept, like mean_v's;
+            if direct is not None:                                    # d lbs through P = solve_backward(G), on every rank
+                s.lbs.grad = direct + s.lbs.grad if s.lbs.grad is not None else direct
         mean_g = flat[o:o + gm.numel()].view_as(gm)
         o += gm.numel()
         if s.mean_v.requires_grad:

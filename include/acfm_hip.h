@@ -168,7 +168,9 @@ int acfm_camera_mirror(const float* cams, int R, float* out, void* stream);
  * row r = g*N + n reads tables[selected ? selected[r] : g][frames_idx[n]] (tables: HOST array of n_tables <= 32 device
  * pointers to [n_frames,7] f32; selected [R] i64 or NULL: main.py:541-548's top-k choice).  backward: grad_tables[t]
  * ([n_frames,7], HOST array of device pointers, NULL entries skipped) are WRITTEN -- zero except the rows the batch
- * looked up, like nn.Embedding's dense gradient. */
+ * looked up, like nn.Embedding's dense gradient.
+ * Out-of-range ids (frames_idx outside [0, n_frames), selected outside [0, n_tables): nn.Embedding raises there) are never
+ * dereferenced: the forward writes a NaN camera for such a row, the backward skips it. */
 int acfm_camera_pipeline_tables(const void* const* tables, int n_tables, int n_frames, const int64_t* frames_idx,
                                 const int64_t* selected, const int64_t* mirror_flag, const float* transforms, int R,
                                 int N, float scale_lr_decay, float* cams, void* stream);
@@ -192,14 +194,19 @@ int acfm_camera_normalize_backward(const float* cam_raw, const float* grad_cams,
  * (pred_v_n = mean_v + P delta_n, acfm_deform_apply).  K_h <= 32.
  * The workspace keeps the factor: acfm_deform_solve_backward turns grad_P [V,K_h] into
  * grad_lbs [V,K_h] (L carries no gradient, geom_utils.py:245).  acfm_deform_solve_info copies
- * the factorisation status to the host (0 = ok, else 1 + first row of the 32-row tile with a
- * non-positive pivot; the reference's torch.cholesky raises there) and synchronises the stream. */
+ * the factorisation status to the host and synchronises the stream: 0 = ok; bit ACFM_SOLVE_INFO_HANDOFF set = a
+ * hand-off wait of the single-launch factorisation expired (a starved wave: P holds NaNs; re-run the solve);
+ * otherwise the low bits are 1 + first row of the 32-row tile with a non-positive pivot (the reference's
+ * torch.cholesky raises there).  acfm_deform_solve_info_offset: byte offset of that int32 status word inside the
+ * workspace, for callers that copy it without blocking (ops.py polls it that way between steps). */
+#define ACFM_SOLVE_INFO_HANDOFF 0x40000000
 size_t acfm_deform_solve_workspace_bytes(int V, int Kh);
 int acfm_deform_solve(const float* L, const float* lbs, int V, int Kh, float* P, void* ws, size_t ws_bytes,
                       void* stream);
 int acfm_deform_solve_backward(const float* grad_P, int V, int Kh, void* ws, size_t ws_bytes, float* grad_lbs,
                                void* stream);
 int acfm_deform_solve_info(const void* ws, size_t ws_bytes, int V, int* info_host, void* stream);
+size_t acfm_deform_solve_info_offset(int V);
 
 /* ---- rasterisation workspace -------------------------------------------------------
  * Scratch of one render call of N meshes with V verts and F faces each at H x H pixels

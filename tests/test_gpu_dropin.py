@@ -1,0 +1,241 @@
+"""GPU tests of the drop-in boundary as the reference's own callers use it: the renderers and
+Boundaries_Loss wrapped in torch.nn.DataParallel (multiframe/main.py:183-193, 326), the literal call sequence of
+ShapeTrainer.forward (main.py:616-720: renderer(...), mirror_sample's flip of mask_pred, l1_loss(reduce=False), the texture
+MSE written as torch ops, edt_loss(reduce=False), boundaries_fn(...)) with the default (lazy) pix_to_face, and the test-time
+refinement's sequence (predictor.py:313-320, reduce=True)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import batch_verts, make_cams
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _d():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _inputs(meshes, name, N, H, R, seed, d):
+    rng = np.random.default_rng(seed)
+    v, f = meshes[name + "_v"], meshes[name + "_f"]
+    verts = batch_verts(v, N, rng, 0.01)
+    cams = make_cams(N, rng, extent=float(np.abs(v).max()))
+    gt = (rng.uniform(size=(N, H, H)) > 0.5).astype(np.float32)
+    edt = rng.uniform(0, 3, (N, 1, H, H)).astype(np.float32)
+    img = rng.uniform(0, 1, (N, 3, H, H)).astype(np.float32)
+    bds = np.concatenate([rng.uniform(-0.8, 0.8, (N, 40, 2)), (rng.uniform(size=(N, 40, 1)) > 0.2)], -1).astype(np.float32)
+    atlas = rng.uniform(0, 1, (N, f.shape[0], R, R, 3)).astype(np.float32)
+    t = lambda x: torch.tensor(x, device=d)
+    return dict(verts=verts, cams=cams, f=f, gt=t(gt), edt=t(edt), img=t(img), bds=t(bds), atlas_np=atlas,
+                faces=torch.from_numpy(f).to(d)[None].repeat(N, 1, 1), gt_np=gt, edt_np=edt, bds_np=bds)
+
+
+def _reference_sequence(I, renderer, tex_renderer, boundaries_fn, L, d, project_points):
+    """main.py:616-720 with num_guesses = 1, names as there.  -> (per-term dict, grads, pix_to_face)"""
+    pred_v = torch.tensor(I["verts"], device=d, requires_grad=True)
+    proj_cam = torch.tensor(I["cams"], device=d, requires_grad=True)
+    textures = torch.tensor(I["atlas_np"], device=d, requires_grad=True)
+    faces, masks, imgs = I["faces"], I["gt"], I["img"]
+    mask_pred, pix_to_face = renderer(pred_v, faces, proj_cam)
+    texture_pred, _, _ = tex_renderer(pred_v.detach(), faces, proj_cam, textures=textures)
+    mask_pred_flip = torch.flip(mask_pred, dims=(2,))                                   # mirror_sample, main.py:98
+    mask_loss = L.l1_loss(mask_pred, masks, reduce=False)                               # :644
+    tex_l1 = F.mse_loss(texture_pred * masks.unsqueeze(1), imgs * masks.unsqueeze(1), reduction='none')   # :655-661
+    tex_l1 = tex_l1.mean((1, 2, 3))
+    pred_proj = project_points(pred_v, proj_cam)                                        # :715
+    edt_loss = L.edt_loss(mask_pred, I["edt"], reduce=False)                            # :716
+    bdt_loss = boundaries_fn(pred_proj, I["bds"], faces, pix_to_face, reduce=False)     # :718
+    total = (mask_loss + 0.1 * (edt_loss + bdt_loss) + 0.5 * tex_l1).mean()
+    total.backward()
+    terms = dict(mask=mask_pred.detach(), flip=mask_pred_flip.detach(), l1=mask_loss.detach(), tex=tex_l1.detach(),
+                 edt=edt_loss.detach(), bdt=bdt_loss.detach(), total=total.detach(), img=texture_pred.detach())
+    return terms, (pred_v.grad, proj_cam.grad, textures.grad), pix_to_face
+
+
+@pytest.mark.parametrize("name,N,H", [("bird", 4, 96), ("horse", 3, 64)])
+def test_reference_call_sequence_through_data_parallel(meshes, name, N, H):
+    """The import-only swap of INTEGRATION.md section 2, run: DataParallel-wrapped NeuralRenderer (twice, as `renderer` and
+    `tex_renderer`) and DataParallel(Boundaries_Loss()) called exactly as main.py does, default renderer (lazy
+    pix_to_face).  Must not raise; every term, image and gradient equals the unwrapped modules' (bit for bit forward;
+    gradients to the float atomics' summation order) and the oracle's; pix_to_face is NOT materialised by the scatter;
+    the silhouette backward forms the summed l1 + edt gradient itself (no k_mask_losses_bwd launch, no [N,H,W]
+    gradient image) although the two losses are separate operators on views the reference's functions create."""
+    from acfm_video_3d_reconstruction_amd import _lib, ops
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _d()
+    I = _inputs(meshes, name, N, H, 3, 7 + N, d)
+    renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()                          # main.py:183-184
+    tex_renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()                      # :191-193
+    boundaries_fn = torch.nn.DataParallel(L.Boundaries_Loss())                          # :325-326
+    lib = _lib.lib()
+    lib.acfm_prof_enable(1)
+    try:
+        terms, grads, p2f = _reference_sequence(I, renderer, tex_renderer, boundaries_fn, L, d, renderer.module.project_points)
+        torch.cuda.synchronize()
+        ran = _lib.prof_collect()
+    finally:
+        lib.acfm_prof_enable(0)
+    assert isinstance(p2f, ops.LazyPixToFace) and not p2f.is_materialized, "the scatter materialised pix_to_face"
+    assert "k_mask_losses_bwd" not in ran and ran["k_sil_bwd"][1] == 1 and ran["k_mask_losses"][1] == 2, ran
+    assert "k_visible" not in ran, "the boundary loss lost the fused visibility bitmap on its way through scatter"
+
+    # the same sequence on the bare modules
+    bare, bare_b = NeuralRenderer(H), L.Boundaries_Loss()
+    t2, g2, p2 = _reference_sequence(I, bare, bare, bare_b, L, d, bare.project_points)
+    for k in terms:
+        assert torch.equal(terms[k], t2[k]), k
+    for a, b in zip(grads, g2):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    assert torch.equal(p2f[..., 0], p2[..., 0])
+    # ... and with the image gradients written out (LAZY_GRADS off): the plain operators' path
+    old = ops.LAZY_GRADS[0]
+    ops.LAZY_GRADS[0] = False
+    try:
+        _, g3, _ = _reference_sequence(I, bare, bare, bare_b, L, d, bare.project_points)
+    finally:
+        ops.LAZY_GRADS[0] = old
+    for a, b in zip(grads, g3):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+    # the oracle: render, losses and the gradient of the same total
+    ref_mask, ref_p2f = O.sil_render(I["verts"], I["f"], I["cams"], H)
+    np.testing.assert_array_equal(p2f[..., 0].cpu().numpy(), ref_p2f[..., 0])
+    np.testing.assert_allclose(terms["mask"].cpu().numpy(), ref_mask, atol=1e-6)
+    np.testing.assert_array_equal(terms["flip"].cpu().numpy(), terms["mask"].cpu().numpy()[:, :, ::-1])
+    np.testing.assert_allclose(terms["l1"].cpu().numpy(), np.abs(ref_mask - I["gt_np"]).reshape(N, -1).mean(-1), rtol=1e-5)
+    np.testing.assert_allclose(terms["edt"].cpu().numpy(), (ref_mask * I["edt_np"][:, 0]).reshape(N, -1).mean(-1), rtol=1e-5)
+    ri, _, _, _ = O.tex_render(I["verts"], I["f"], I["cams"], I["atlas_np"], H)
+    np.testing.assert_allclose(terms["img"].cpu().numpy(), ri, atol=1e-6)
+    m1 = I["gt_np"][:, None]
+    np.testing.assert_allclose(terms["tex"].cpu().numpy(), ((ri * m1 - I["img"].cpu().numpy() * m1) ** 2).reshape(N, -1).mean(-1),
+                               rtol=1e-5)
+    # d total / d mask = (sign(m - gt) + 0.1 edt) / (N H W); the boundary term adds through the projected vertices
+    gm = (np.sign(ref_mask - I["gt_np"]) + 0.1 * I["edt_np"][:, 0]).astype(np.float32) / (N * H * H)
+    gv, gc, _, _ = O.sil_render_backward(I["verts"], I["f"], I["cams"], H, gm)
+    tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+    tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+    b_only = (0.1 * L.bds_loss(bare.project_points(tv, tc), I["bds"], I["faces"], p2, reduce=False)).mean()
+    b_only.backward()
+    want_v, want_c = gv + tv.grad.cpu().numpy(), gc + tc.grad.cpu().numpy()
+    np.testing.assert_allclose(grads[0].cpu().numpy(), want_v, atol=1e-4 * np.abs(want_v).max())
+    np.testing.assert_allclose(grads[1].cpu().numpy(), want_c, atol=1e-4 * np.abs(want_c).max())
+
+    # any other slot still works after the trip through DataParallel, and only now costs the second render
+    assert torch.equal(p2f[..., 3].cpu(), torch.from_numpy(ref_p2f[..., 3])) and p2f.is_materialized
+
+
+def test_data_parallel_replicas_and_gather(meshes):
+    """nn.DataParallel with two replicas (both on this card: device_ids=[0, 0] -- the scatter / replicate / per-replica
+    THREADS / gather machinery of main.py:183-193 on a one-GPU box): outputs are gathered plain tensors equal to the
+    bare module's, the module-level caches survive two threads rendering at once, gradients flow back through
+    Gather / Scatter."""
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _d()
+    N, H = 6, 64
+    I = _inputs(meshes, "bird", N, H, 2, 23, d)
+    bare = NeuralRenderer(H)
+    dp = torch.nn.DataParallel(NeuralRenderer(H), device_ids=[0, 0]).cuda()
+    dpb = torch.nn.DataParallel(L.Boundaries_Loss(), device_ids=[0, 0])
+    tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+    tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+    Fn = I["f"].shape[0]
+    for _ in range(3):                                   # threads race on the caches: repeat
+        mask, p2f = dp(tv, I["faces"], tc)
+        m0, p0 = bare(tv, I["faces"], tc)
+        assert torch.equal(mask, m0) and tuple(p2f.shape) == (N, H, H, 20)
+        # packed ids are relative to the replica's own batch (as in the reference: every replica packs its chunk, and
+        # bds_loss re-derives the offsets from its chunk of `faces`, loss_utils.py:217)
+        want = p0.materialize().clone()
+        want[N // 2:][want[N // 2:] >= 0] -= (N // 2) * Fn
+        assert torch.equal(p2f, want)
+        atlas = torch.tensor(I["atlas_np"], device=d)
+        img, sil, p1 = dp(tv.detach(), I["faces"], tc, textures=atlas)
+        i0, s0, q0 = bare(tv.detach(), I["faces"], tc, textures=atlas)
+        assert torch.equal(img, i0) and torch.equal(sil, s0) and torch.equal(p1, q0)
+    proj = bare.project_points(tv, tc)
+    m0, p0 = bare(tv, I["faces"], tc)
+    b0 = L.bds_loss(proj, I["bds"], I["faces"], p0, reduce=False)
+    b = dpb(proj, I["bds"], I["faces"], p0, reduce=False)              # a lazy pix_to_face scattered into two replicas
+    assert torch.equal(b, b0) and not p0.is_materialized
+    b1 = dpb(proj, I["bds"], I["faces"], p2f, reduce=False)            # the gathered plain tensor (replica-local ids), as in main.py
+    assert torch.equal(b1, b0)
+    (L.l1_loss(mask, I["gt"]) + 0.1 * b.mean()).backward()
+    gv, gc = tv.grad.clone(), tc.grad.clone()
+    tv.grad = tc.grad = None
+    (L.l1_loss(m0, I["gt"]) + 0.1 * b0.mean()).backward()
+    assert float((gv - tv.grad).abs().max()) <= 2e-6 * float(tv.grad.abs().max())
+    assert float((gc - tc.grad).abs().max()) <= 2e-6 * float(tc.grad.abs().max())
+
+
+def test_refinement_call_sequence_reduce_true(meshes):
+    """predictor.py:313-320: renderer (not DataParallel there), l1_loss / edt_loss with reduce=True, Boundaries_Loss: the
+    summed gradient of the two scalar silhouette terms reaches the render's backward unformed as well."""
+    from acfm_video_3d_reconstruction_amd import _lib
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _d()
+    N, H = 3, 64
+    I = _inputs(meshes, "cow", N, H, 2, 5, d)
+    ren, bfn = NeuralRenderer(H), L.Boundaries_Loss()
+
+    def run():
+        tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+        tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+        mask_pred, pix_to_face = ren(tv, I["faces"], tc)
+        mask_loss = L.l1_loss(mask_pred, I["gt"])
+        pred_proj = ren.project_points(tv, tc)
+        edt_loss = L.edt_loss(mask_pred, I["edt"])
+        bdt_loss = bfn(pred_proj, I["bds"], I["faces"], pix_to_face)
+        total = mask_loss + 0.5 * (edt_loss + bdt_loss)
+        total.backward()
+        return total.detach(), tv.grad, tc.grad, mask_pred.detach()
+    lib = _lib.lib()
+    lib.acfm_prof_enable(1)
+    try:
+        total, gv, gc, mask = run()
+        torch.cuda.synchronize()
+        ran = _lib.prof_collect()
+    finally:
+        lib.acfm_prof_enable(0)
+    assert "k_mask_losses_bwd" not in ran and ran["k_sil_bwd"][1] == 1, ran
+    m = mask.cpu().numpy()
+    gm = (np.sign(m - I["gt_np"]) + 0.5 * I["edt_np"][:, 0]).astype(np.float32) / (N * H * H)
+    ov, oc, _, _ = O.sil_render_backward(I["verts"], I["f"], I["cams"], H, gm)
+    tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+    tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+    (0.5 * L.bds_loss(ren.project_points(tv, tc), I["bds"], I["faces"], ren(tv, I["faces"], tc)[1])).backward()
+    want_v, want_c = ov + tv.grad.cpu().numpy(), oc + tc.grad.cpu().numpy()
+    np.testing.assert_allclose(gv.cpu().numpy(), want_v, atol=1e-4 * np.abs(want_v).max())
+    np.testing.assert_allclose(gc.cpu().numpy(), want_c, atol=1e-4 * np.abs(want_c).max())
+
+
+def test_lazy_pix_to_face_made_inside_a_capture_refuses_to_form_outside_it(meshes):
+    """A LazyPixToFace rendered while a hipGraph is being captured has the capture's buffers for inputs: forming its
+    other slots after the capture would render whatever those buffers hold -- it raises and names the alternative."""
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _d()
+    N, H = 2, 64
+    I = _inputs(meshes, "bird", N, H, 2, 3, d)
+    tv, tc = torch.tensor(I["verts"], device=d), torch.tensor(I["cams"], device=d)
+    ren = NeuralRenderer(H)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ren(tv, I["faces"], tc)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mask, p2f = ren(tv, I["faces"], tc)
+        plane = p2f[..., 0]
+    g.replay()
+    torch.cuda.synchronize()
+    ref_mask, ref_p2f = O.sil_render(I["verts"], I["f"], I["cams"], H)
+    np.testing.assert_array_equal(plane.cpu().numpy(), ref_p2f[..., 0])
+    with pytest.raises(RuntimeError, match="hipGraph capture"):
+        p2f[..., 1]

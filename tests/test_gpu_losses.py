@@ -654,6 +654,27 @@ def test_camera_pipeline_from_the_embedding_tables():
                 np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
     with pytest.raises(ValueError):
         ops.camera_pipeline_tables(tabs[:2], fi, mf, tr, 0.05, num_guesses=3)
+    # ids outside the tables (a data-loader bug; nn.Embedding raises): never dereferenced -- that row's camera is NaN, it
+    # gets no gradient, every other row and every table cell is untouched; check=True raises on the host instead
+    for bad_fi, bad_sel in ((fi.clone().index_put_((torch.tensor(1), torch.tensor(0)), torch.tensor(F + 100000, device=d)), None),
+                            (fi.clone().index_put_((torch.tensor(2), torch.tensor(1)), torch.tensor(-3, device=d)), None),
+                            (fi, torch.full((3, B, T), 0, device=d).index_put_(
+                                (torch.tensor(1), torch.tensor(3), torch.tensor(0)), torch.tensor(Gall + 7, device=d)))):
+        k = Gall if bad_sel is None else 3
+        for t in tabs:
+            t.grad = None
+        good = ops.camera_pipeline_tables(tabs, fi, mf, tr, 0.05, num_guesses=k,
+                                          selected=None if bad_sel is None else torch.zeros_like(bad_sel)).detach()
+        out = ops.camera_pipeline_tables(tabs, bad_fi, mf, tr, 0.05, num_guesses=k, selected=bad_sel)
+        nan_rows = torch.isnan(out).any(1)
+        assert int(nan_rows.sum()) == (Gall if bad_sel is None else 1) and torch.isnan(out[nan_rows]).all()
+        assert torch.equal(out[~nan_rows].detach(), good[~nan_rows])
+        torch.nan_to_num(out, nan=0.0).sum().backward()
+        torch.cuda.synchronize()
+        assert all(t.grad is None or torch.isfinite(t.grad).all() for t in tabs)
+        with pytest.raises(IndexError):
+            ops.camera_pipeline_tables(tabs, bad_fi, mf, tr, 0.05, num_guesses=k, selected=bad_sel, check=True)
+    ops.camera_pipeline_tables(tabs, fi, mf, tr, 0.05, check=True)
     # the mirrored pose of decoded cameras (what the texture branch renders under): one kernel == harness's chain of
     # pytorch3d.transforms calls (property-tested on the CPU, and against the oracle inside the composed tests)
     from acfm_video_3d_reconstruction_amd import harness

@@ -596,8 +596,8 @@ def test_silhouette_backward_twice_on_one_workspace(meshes):
 
 def test_setup_take_over_never_crosses_a_graph_replay_or_a_stream(meshes):
     """Eager silhouette render -> a hipGraph replay rewrites the vertex buffer in place (no version bump) -> eager
-    texture render of the same tensor: the cached face setup must NOT be taken over (ops._EPOCH is bumped by every
-    CUDAGraph.replay); the result is the oracle's render of the NEW geometry.  Likewise a texture render on another
+    texture render of the same tensor: the cached face setup must NOT be taken over (the replay is announced with
+    ops.graph_replay = invalidate_setups() + replay; torch itself is not patched); the result is the oracle's render of the NEW geometry.  Likewise a texture render on another
     stream, and after ops.invalidate_setups() / with share_setup(False), sets up by itself."""
     from acfm_video_3d_reconstruction_amd import ops
     d = _dev()
@@ -624,7 +624,8 @@ def test_setup_take_over_never_crosses_a_graph_replay_or_a_stream(meshes):
     assert ops._shared_setup(tv, tc, tf, H, 0.0) is not None             # plain eager pair: shared
     ver = tv._version
     src.copy_(torch.tensor(verts_b, device=d))
-    g.replay()                                                           # tv now holds verts_b, same address, same version
+    assert not hasattr(torch.cuda.CUDAGraph.replay, "_acfm_wrapped")     # round 2 edited torch here; no more
+    ops.graph_replay(g)                                                  # tv now holds verts_b, same address, same version
     torch.cuda.synchronize()
     assert tv._version == ver and np.array_equal(tv.cpu().numpy(), verts_b)
     assert ops._shared_setup(tv, tc, tf, H, 0.0) is None

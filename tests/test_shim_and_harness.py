@@ -1,6 +1,7 @@
 """CPU: host-side logic around the kernels -- PyTorch3D API shim, trainer harness helpers,
 deformation solver -- against the oracle and the reference's golden outputs."""
 import io
+import os
 
 import numpy as np
 import torch
@@ -253,3 +254,135 @@ def test_lazy_grad_dispatch():
     assert g2.take("mask_losses", img2) is not None          # (same version counter object: payload image IS img2) ...
     g3 = LazyGrad(img2, "mask_losses", (img2.clone(), None, None, 2, None), lambda: grad)
     assert g3.take("mask_losses", img2) is None              # ... a different storage is refused
+
+
+def test_lazy_pix_to_face_survives_batch_splits_and_scatter():
+    """What nn.DataParallel's scatter does to every tensor argument (main.py:326, 718: Boundaries_Loss gets pix_to_face
+    through it, also on ONE device) is `chunk` along the batch dimension: the parts of an unformed LazyPixToFace stay
+    unformed, carry their rows of the visibility bitmap, answer `[..., 0]` from their rows of the stored plane and
+    form the parent -- once -- only when another slot is read."""
+    import copy
+    import torch
+    from acfm_video_3d_reconstruction_amd.ops import LazyPixToFace
+    N, H, K, V = 6, 4, 5, 7
+    full = torch.arange(N * H * H * K, dtype=torch.int64).reshape(N, H, H, K)
+    vis = torch.arange(N * V, dtype=torch.uint8).reshape(N, V)
+    calls = []
+
+    def make():
+        calls.append(1)
+        return full
+    p = LazyPixToFace(full[..., :1].contiguous(), K, make, vis)
+    parts = p.chunk(3, 0)
+    assert len(parts) == 3 and all(isinstance(q, LazyPixToFace) and tuple(q.shape) == (2, H, H, K) for q in parts)
+    assert torch.equal(parts[1][..., 0], full[2:4, ..., 0]) and torch.equal(parts[1]._acfm_vis, vis[2:4]) and not calls
+    whole = p.chunk(1, 0)[0]                                                        # one device: all rows, still unformed
+    assert isinstance(whole, LazyPixToFace) and tuple(whole.shape) == (N, H, H, K) and torch.equal(whole._acfm_vis, vis)
+    assert isinstance(p.split(N, 0)[0], LazyPixToFace) and isinstance(p[0:N], LazyPixToFace) and not calls
+    a, b = p.split([4, 2], 0)
+    assert isinstance(b, LazyPixToFace) and torch.equal(b[..., :1], full[4:, ..., :1]) and torch.equal(b._acfm_vis, vis[4:])
+    q = p[1:3]
+    assert isinstance(q, LazyPixToFace) and torch.equal(q[..., 0], full[1:3, ..., 0])
+    one = p[2]
+    assert isinstance(one, LazyPixToFace) and tuple(one.shape) == (H, H, K) and torch.equal(one[..., 0], full[2, ..., 0])
+    assert not calls and not p.is_materialized
+    assert torch.equal(parts[2][..., 3], full[4:6, ..., 3]) and len(calls) == 1 and p.is_materialized   # parent formed once
+    assert torch.equal(one[..., 1], full[2, ..., 1]) and len(calls) == 1
+    c = copy.deepcopy(p)
+    assert type(c) is torch.Tensor and torch.equal(c, full)
+
+
+def test_lazy_grad_views_and_sums_stay_unformed():
+    """The reference hands the silhouette-loss operators views of the rendered mask (`mask.view(N, -1)`, `mask[:, None]`,
+    loss_utils.py:18-32, 72-77) and sums the gradients of l1_loss and edt_loss on the same mask (main.py:644, 716):
+    the view backwards and that sum keep an ops.LazyGrad unformed; the merged gradient names both references and the
+    sum of the upstream gradients, each operator's columns masked by the references it had."""
+    import torch
+    from acfm_video_3d_reconstruction_amd.ops import LazyGrad
+    N, H = 2, 4
+    img = torch.rand(N, H, H)
+    gt, edt = torch.rand(N, H * H), torch.rand(N, H * H)
+    ga, gb = torch.rand(N, H, H), torch.rand(N, H, H)
+    calls = []
+    go1 = torch.tensor([[1., 2., 3., 4.]] * N)
+    go2 = torch.tensor([[10., 20., 30., 40.]] * N)
+    l1 = LazyGrad(img, "mask_losses", (img, gt, None, N, go1), lambda: (calls.append("a"), ga)[1])
+    ed = LazyGrad(img, "mask_losses", (img, None, edt, N, go2), lambda: (calls.append("b"), gb)[1])
+    # shape-only views (what ViewBackward / UnsqueezeBackward do to the gradient)
+    v = l1.view(N, -1)
+    assert type(v) is LazyGrad and tuple(v.shape) == (N, H * H) and not calls
+    back = v.view(N, H, H)
+    assert back.take("mask_losses", img)[0] is img
+    u = l1.unsqueeze(1)
+    assert type(u) is LazyGrad and tuple(u.shape) == (N, 1, H, H) and type(u.squeeze(1)) is LazyGrad and not calls
+    assert u.take("mask_losses", img) is not None          # same storage, element count and version
+    # the sum of two operators' gradients on the same mask
+    s = l1 + ed
+    assert type(s) is LazyGrad and not s.is_materialized and not calls
+    m, g, e, rb, go = s.take("mask_losses", img)
+    assert m is img and g is gt and e is edt and rb == N
+    assert torch.equal(go, torch.tensor([[1., 2., 3., 40.]] * N))       # l1's columns 0-2, edt's column 3
+    assert torch.equal(s + 0, ga + gb) and sorted(calls) == ["a", "b"]   # formed after all: the plain sum
+    # different masks / references do not merge: the plain path
+    calls.clear()
+    other = LazyGrad(img, "mask_losses", (img.clone(), None, edt, N, go2), lambda: gb)
+    assert type(l1_ := LazyGrad(img, "mask_losses", (img, gt, None, N, go1), lambda: ga) + other) is torch.Tensor and torch.equal(l1_, ga + gb)
+    x = LazyGrad(img, "mask_losses", (img, gt, None, N, go1), lambda: ga)
+    y = LazyGrad(img, "mask_losses", (img, gt.clone(), None, N, go2), lambda: gb)
+    assert type(x + y) is torch.Tensor
+    # a reshaped view formed later has the view's shape
+    z = LazyGrad(img, "mask_losses", (img, gt, None, N, go1), lambda: ga).view(N, -1)
+    assert torch.equal(z * 1, ga.reshape(N, -1))
+
+
+def test_perceptual_texture_loss_constructs_around_lpips(monkeypatch):
+    """loss_utils.py:359-383: PerceptualTextureLoss_v2 is glue around the third-party `lpips` package.  predictor.py:108 and
+    main.py:334 construct it: with the package present (a stand-in module here) construction and the call work and
+    reproduce the reference's arithmetic; without it the constructor raises an ImportError that names the package."""
+    import sys
+    import types
+    import pytest
+    import torch
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils
+    monkeypatch.setitem(sys.modules, "lpips", None)
+    with pytest.raises(ImportError, match="lpips"):
+        loss_utils.PerceptualTextureLoss_v2()
+
+    class FakeLPIPS(torch.nn.Module):
+        def __init__(self, net="alex", lpips=False, spatial=False):
+            super().__init__()
+            assert net == "alex" and spatial is True and lpips is False
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, a, b):
+            return self.w * (a - b).abs().mean(1, keepdim=True)       # [B,1,H,W] "distance map"
+    fake = types.ModuleType("lpips")
+    fake.LPIPS = FakeLPIPS
+    monkeypatch.setitem(sys.modules, "lpips", fake)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    fn = loss_utils.PerceptualTextureLoss_v2()
+    g = torch.Generator().manual_seed(0)
+    pred, img = torch.rand(3, 3, 8, 8, generator=g), torch.rand(3, 3, 8, 8, generator=g)
+    mp, mg = torch.rand(3, 8, 8, generator=g), (torch.rand(3, 8, 8, generator=g) > 0.4).float()
+    per = fn(pred, img, mp, mg, reduce=False)
+    m = mg[:, None]
+    want = ((2 * pred * m - 1) - (2 * img * m - 1)).abs().mean(1, keepdim=True) * m
+    want = want.mean(-2, keepdim=True).mean(-1, keepdim=True).squeeze(-1).squeeze(-1).squeeze(-1)
+    assert per.shape == (3,) and torch.allclose(per, want, atol=1e-6)
+    assert torch.allclose(fn(pred, img, mp, mg), want.mean(), atol=1e-6)
+
+
+def test_solve_status_word_decoding():
+    """ops.decode_solve_info: the status word of acfm_deform_solve.  0 = ok; ACFM_SOLVE_INFO_HANDOFF (bit 30) = an expired
+    hand-off wait of the single-launch factorisation -- reported as such, not as 'pivot row 1073741823' --; otherwise
+    1 + the first row of the tile with a non-positive pivot (also when both are set: the hand-off message wins, the
+    pivot may be a consequence of the NaNs)."""
+    import re
+    from acfm_video_3d_reconstruction_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "acfm_hip.h")).read()
+    assert int(re.search(r"#define ACFM_SOLVE_INFO_HANDOFF (0x[0-9a-fA-F]+)", hdr).group(1), 16) == ops.SOLVE_INFO_HANDOFF
+    assert ops.decode_solve_info(0) is None
+    assert "row 64" in ops.decode_solve_info(65) and "positive definite" in ops.decode_solve_info(65)
+    for word in (ops.SOLVE_INFO_HANDOFF, ops.SOLVE_INFO_HANDOFF | 33):
+        msg = ops.decode_solve_info(word)
+        assert "hand-off" in msg and "positive definite" not in msg and "1073741823" not in msg
