@@ -685,6 +685,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
     const bool in_box = have &&
         !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
     DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(in_box))); DIAG_ADD(10, __popcll(__ballot(have)));
+    DIAG_ADD(12, __popcll(__ballot(have) & 0x0001000100010001ull));   // (group, face) pairs walked
     body(cur, in_box, i);
   }
 }
@@ -1660,6 +1661,12 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
 #endif
         DIAG_ADD(7, __popcll(__ballot(true))); DIAG_ADD(11, 1);
+#ifdef ACFM_DIAG_COUNT
+        {   // (group, face) pairs with at least one accepting pixel
+          const unsigned long long am = __ballot(true);
+          DIAG_ADD(13, ((am & 0xffffull) != 0) + ((am & 0xffff0000ull) != 0) + ((am & 0xffff00000000ull) != 0) + ((am >> 48) != 0));
+        }
+#endif
         float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma, sig_scale);
 #ifdef ACFM_DIAG_NO_INSERT
         if (x < key[0]) { key[0] = x; q[0] = xq; }

@@ -87,8 +87,11 @@ def test_reference_call_sequence_through_data_parallel(meshes, name, N, H):
     # the same sequence on the bare modules
     bare, bare_b = NeuralRenderer(H), L.Boundaries_Loss()
     t2, g2, p2 = _reference_sequence(I, bare, bare, bare_b, L, d, bare.project_points)
-    for k in terms:
-        assert torch.equal(terms[k], t2[k]), k
+    for k in terms:     # images bit for bit; the per-mesh sums to the order of k_mask_losses' float atomics
+        if k in ("mask", "flip", "img"):
+            assert torch.equal(terms[k], t2[k]), k
+        else:
+            assert torch.allclose(terms[k], t2[k], rtol=2e-6, atol=0), k
     for a, b in zip(grads, g2):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
     assert torch.equal(p2f[..., 0], p2[..., 0])
@@ -157,6 +160,8 @@ def test_data_parallel_replicas_and_gather(meshes):
         atlas = torch.tensor(I["atlas_np"], device=d)
         img, sil, p1 = dp(tv.detach(), I["faces"], tc, textures=atlas)
         i0, s0, q0 = bare(tv.detach(), I["faces"], tc, textures=atlas)
+        q0 = q0.clone()
+        q0[N // 2:][q0[N // 2:] >= 0] -= (N // 2) * Fn          # (replica-local packed ids again)
         assert torch.equal(img, i0) and torch.equal(sil, s0) and torch.equal(p1, q0)
     proj = bare.project_points(tv, tc)
     m0, p0 = bare(tv, I["faces"], tc)

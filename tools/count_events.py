@@ -20,7 +20,8 @@ raw.acfm_debug_counters(c, 1)
 mask, p2f = ops.sil_render(verts, faces, cams, H); torch.cuda.synchronize()
 raw.acfm_debug_counters(c, 0)
 names = ["blocks with work", "walk calls", "candidates (sum list_n)", "walk iterations (wave)", "lanes in_box", "iterations reaching stage 2",
-         "lanes live (stage 2)", "lanes accepted", "insertion blocks executed", "insertion block tests", "lanes having a face", "iterations inserting"]
+         "lanes live (stage 2)", "lanes accepted", "insertion blocks executed", "insertion block tests", "lanes having a face", "iterations inserting",
+         "(group, face) pairs walked", "(group, face) pairs with an accepting pixel"]
 for i, n in enumerate(names): print("%-32s %12d" % (n, c[i]))
 it = c[3]
 print("per iteration: lanes with a face %.1f, in_box %.1f, live %.1f (of the %.0f%% of iterations that reach stage 2), accepted %.1f; "
