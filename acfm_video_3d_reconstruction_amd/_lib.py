@@ -49,6 +49,8 @@ SIGNATURES = {
     "acfm_stream_capture_id": (_i, [_vp, _vp]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                               _sz, _vp, _vp]),
+    "acfm_sil_forward_prefill": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                      _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
                                _sz, _i, _vp, _vp]),
     "acfm_sil_loss_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
@@ -165,7 +167,7 @@ class raster_tuning:
     Tests use it to force the split / unsplit kernels and every grid divisor; the library itself keeps
     no tuning state."""
 
-    def __init__(self, split=-3, grid_div=(0, 0, 0), deterministic=False, record_cover=None):
+    def __init__(self, split=-5, grid_div=(0, 0, 0), deterministic=False, record_cover=None):
         """deterministic=True: the silhouette backward accumulates in fixed point (bit-reproducible run to run).
         record_cover: True / False forces ACFM_RECORD_COVER (the silhouette render leaves the nearest covering face
         per pixel for a texture render that takes its workspace over) on / off; None lets ops.py decide -- on while
@@ -197,14 +199,14 @@ def tuning_ptr(t):
 def with_f16(t, on):
     """The tuning in effect with flags bit 1 (ACFM_STORE_F16) set or cleared: a fresh structure."""
     if t is None:
-        return RasterTuning(-3, (_i * 3)(0, 0, 0), 2) if on else None
+        return RasterTuning(-5, (_i * 3)(0, 0, 0), 2) if on else None
     return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~2) | (2 if on else 0))
 
 
 def with_cover(t, on):
     """The tuning in effect with flags bit 2 (ACFM_RECORD_COVER) set or cleared: a fresh structure (None = defaults)."""
     if t is None:
-        return RasterTuning(-3, (_i * 3)(0, 0, 0), 4) if on else None
+        return RasterTuning(-5, (_i * 3)(0, 0, 0), 4) if on else None
     if bool(t.flags & 4) == bool(on):
         return t
     return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~4) | (4 if on else 0))

@@ -12,8 +12,8 @@
 
 #pragma clang fp contract(off)
 
-#ifndef ACFM_FWD_V2
-#define ACFM_FWD_V2 0   // see acfm_raster.hip
+#ifndef ACFM_EDGE_CONST
+#define ACFM_EDGE_CONST 0   // see acfm_raster.hip
 #endif
 
 #define ACFM_K_EPS 1e-8f   // PyTorch3D kEpsilon
@@ -45,23 +45,20 @@ struct ProfScope {
 constexpr int CTILE = ACFM_CTILE;  // coarse tile side (pixels): k_setup leaves one face bitmask per coarse tile
 
 // Per-face record of the raster workspace (k_setup writes it, the binning of the raster kernels reads it).
-// Two cache lines: the first is all the backward walk needs; the second holds what is constant per FACE in the
-// exact per-pixel test -- the three edge vectors, their squared lengths and refined reciprocals (the operands
-// of the IEEE-exact divisions of point_line_dist / the barycentrics) -- computed once per face in k_setup
-// with the very operations the per-pixel code used to repeat for every pixel, so every per-pixel value is
+// The first cache line is all the backward and nearest-face walks need; ACFM_EDGE_CONST adds what is constant per
+// FACE in the exact per-pixel distance test of the K-nearest forward -- the squared lengths of the three edges and
+// their refined reciprocals (operands of the IEEE-exact division of point_line_dist) -- computed once per face in
+// k_setup with the very operations the per-pixel code used to repeat for every pixel, so every per-pixel value is
 // bit-identical to the unfactored evaluation (and to the oracle).
 struct __attribute__((aligned(64))) FaceRec {
   float4 box;   // (xmin,xmax,ymin,ymax), blur margin included; degenerate face = (inf,-inf,inf,-inf)
   float4 a;     // (x0,y0,x1,x2)   -- (x1,x2), (y1,y2) as register pairs for the packed fp32 pipe
   float4 b;     // (y1,y2,z0,z1)
   float4 c;     // (z2, area, denom = area + kEps, rden = refined 1/denom)
-#if ACFM_FWD_V2   // (second cache line: only the per-pixel-list experiment reads it)
-  float4 e01;   // (x1-x0, y1-y0, |.|^2, refined 1/|.|^2)      edge v0 -> v1
-  float4 e12;   // (x2-x1, y2-y1, |.|^2, refined 1/|.|^2)      edge v1 -> v2
-  float4 e02;   // (x2-x0, y2-y0, |.|^2, refined 1/|.|^2)      edge v0 -> v2
-  float4 sn;    // (s01, s12, s02, flag): s = -sign(area) / |edge| (0 for an edge shorter than 1e-6): edge function
-                // x s = signed distance of the pixel to the edge LINE, positive outside -- the conservative
-                // per-pixel prefilter of the forward kernels; flag = 1 if an edge has |.|^2 <= kEps
+#if ACFM_EDGE_CONST
+  float4 e0;    // (|e01|^2, |e02|^2, 1/|e01|^2, 1/|e02|^2): edges v0->v1 and v0->v2, the pair the packed pipe evaluates
+  float4 e1;    // (|e12|^2, 1/|e12|^2, flag = 1 if any |e|^2 <= kEps (that face takes the unfactored path), -)
+  float4 pad_[2];
 #endif
 };
 
@@ -93,7 +90,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Per-call tuning of the raster launches (AcfmRasterTuning of the C ABI; NULL = these defaults).  There is
 // no process-global knob: every entry point takes its own copy.
 struct Tune {
-  int split = -3;            // split heuristic: < 0 automatic (k_order: split while the longest block > (-split / 2) x mean work per wave slot), 0 never, 1 always
+  int split = -5;            // split heuristic: < 0 automatic (k_order: a block is split when its cost > (-split / 4) x the mean work per wave slot), 0 never, 1 always
   int div[3] = {4, 2, 4};    // workgroups per XCD group = entries / div: [0] K-nearest forward, [1] nearest-face forward, [2] backward
                              // (measured at 64 frames @256^2: K-nearest forward 323 (div 1) / 292 (2) / 287 (4) us)
   bool deterministic = false; // flags bit 0: fixed-point accumulation in the silhouette backward
@@ -115,17 +112,20 @@ static inline bool tune_from(const AcfmRasterTuning* t, Tune& out) {
   return true;
 }
 
-static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_split_mode = -3) {
+static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_split_mode = -5) {
   RasterWs w;
   {
-    // Splitting costs ~25 % more work per split block (four waves bin and merge).  It pays while a
-    // launch is bound by its few heaviest blocks (one 8x8 block of a dense mesh region runs ~250 us,
-    // the work of a whole frame is ~4 us of the chip): up to ~40 frames at 256^2.  Larger launches
-    // are throughput-bound and keep one wave per block (measured at 64 frames: 312 -> 390 us with it).
+    // Splitting costs ~25 % more work per split block (four waves bin and merge) and shortens it ~3x.  It pays for the
+    // blocks that would outlast the launch (k_order decides which, from the cost histogram): whole small launches --
+    // one 8x8 block of a dense mesh region runs ~250 us, the work of a whole frame is ~4 us of the chip --, and the few
+    // dozen heaviest blocks of a large one (64 frames @256^2: the blocks of >= 240 face boxes span the whole 208-us
+    // launch).  Split slots are workgroups that exist whether used or not (4 per slot, an immediate exit if unused):
+    // up to 1024 per XCD group for small launches, 4 per mesh of the group for large ones.
     const int per_group = (N & 7) == 0 ? N / 8 : N;      // meshes per XCD group
     const size_t blocks = (size_t)N * ((H + 7) / 8) * ((H + 7) / 8);
-    const bool on = g_split_mode < 0 ? blocks <= 40960 : g_split_mode > 0;
-    w.split_slots = !on ? 0 : (per_group * 32 < 1024 ? per_group * 32 : 1024);
+    if (g_split_mode == 0) w.split_slots = 0;
+    else if (g_split_mode > 0 || blocks <= 40960) w.split_slots = per_group * 32 < 1024 ? per_group * 32 : 1024;
+    else w.split_slots = per_group * 4 < 256 ? per_group * 4 : 256;
   }
   char* p = (char*)base;
   size_t o = 0;

@@ -70,7 +70,7 @@ constexpr int SETUP_LDS_TILES = 4096;  // counters kept in LDS up to 1024x1024 i
 constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes near this block
 constexpr int ENTRY_SPLIT = 1 << 29;   // order entry flag: a heavy block, rendered by four workgroups (one per 4x4 pixels)
 constexpr int ENTRY_FLAGS = ENTRY_EMPTY | ENTRY_SPLIT;
-constexpr int SPLIT_MAX_CLASS = 2;     // ... if their cost class is at most this (>= 80 face boxes)
+constexpr int SPLIT_MAX_CLASS = 6;     // ... if their cost class is at most this (>= 80 face boxes)
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
 typedef unsigned short fl_t;  // face ids of one mesh (F <= ACFM_MAX_FACES = 65535)
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
@@ -168,20 +168,13 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     {
       const float denom = area + ACFM_K_EPS;
       r.c = make_float4(z2, area, denom, recip_refined(denom));
-#if ACFM_FWD_V2
-      const float sgn = area > 0.f ? -1.0f : 1.0f;
-      float s3[3], flag = 0.f;
-      const float ex[3] = {x1 - x0, x2 - x1, x2 - x0}, ey[3] = {y1 - y0, y2 - y1, y2 - y0};
-      float4 e[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float l2 = ex[k] * ex[k] + ey[k] * ey[k];
-        e[k] = make_float4(ex[k], ey[k], l2, recip_refined(l2));
-        s3[k] = l2 > 1e-12f ? sgn * __builtin_amdgcn_rsqf(l2) : 0.f;
-        if (l2 <= ACFM_K_EPS) flag = 1.0f;
-      }
-      r.e01 = e[0]; r.e12 = e[1]; r.e02 = e[2];
-      r.sn = make_float4(s3[0], s3[1], s3[2], flag);
+#if ACFM_EDGE_CONST
+      // point_line_dist's own operations on (a, b) = (v0, v1), (v0, v2), (v1, v2): bax = bx - ax, l2 = bax bax + bay bay
+      const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
+      const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
+      const bool deg = (l01 <= ACFM_K_EPS) || (l02 <= ACFM_K_EPS) || (l12 <= ACFM_K_EPS);
+      r.e0 = make_float4(l01, l02, recip_refined(l01), recip_refined(l02));
+      r.e1 = make_float4(l12, recip_refined(l12), deg ? 1.0f : 0.0f, 0.0f);
 #endif
     }
     ws.vidx[o] = make_int4(i0, i1, i2, 0);
@@ -277,9 +270,12 @@ int zero_async(void* p, size_t nbytes, hipStream_t st) {
 // The cost of a block is the face count of its 16x16 tile (k_setup); count 0 = no face box comes
 // near: the entry is flagged and the raster kernels write that block's zeros without looking at
 // the mesh at all.
-constexpr int NCLASS = 8;
+constexpr int NCLASS = 12;
+// (the four classes above 160 exist to ORDER the heaviest blocks: at 64 frames the blocks of >= 240 face boxes -- 89 of
+// 15 474, 3 % of the work -- start first and still run for the whole launch; see the split rule in k_order)
 __device__ __forceinline__ int cost_class(int c) {
-  return c >= 160 ? 0 : c >= 112 ? 1 : c >= 80 ? 2 : c >= 56 ? 3 : c >= 36 ? 4 : c >= 20 ? 5 : c >= 1 ? 6 : 7;
+  return c >= 320 ? 0 : c >= 280 ? 1 : c >= 240 ? 2 : c >= 200 ? 3 : c >= 160 ? 4 : c >= 112 ? 5 : c >= 80 ? 6 : c >= 56 ? 7
+       : c >= 36 ? 8 : c >= 20 ? 9 : c >= 1 ? 10 : 11;
 }
 __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int H) {
   const int blocks = (H + RBLK - 1) / RBLK, tiles = (H + CNT_TILE - 1) / CNT_TILE;
@@ -340,22 +336,26 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
     int nw = 0;
     for (int c = 0; c < NCLASS - 1; ++c) nw += s_hist[c];
     ws.n_work[g] = nw;   // the flagged-empty class sits at the end of the order
-    // Split the heaviest blocks over four workgroups each?  It adds ~25 % work to those blocks and
-    // shortens the longest one about 3x: worth it while the group's longest block (in candidate
-    // faces ~ walk iterations) outweighs its total work spread over the XCD's 384 wave slots.
-    // Measured crossover: ~16-32 frames at 256^2 (bird 32, horse and cow 16-24).
-    const int mid[NCLASS] = {200, 136, 96, 68, 46, 28, 10, 0};
+    // Split the heaviest blocks over four workgroups each?  It adds ~25 % work to those blocks and shortens them about
+    // 3x.  A launch lasts at least as long as its longest block (per-block stamps at 64 frames @256^2: the blocks of
+    // ~300 face boxes start at t = 0 and end with the kernel, 225 us, while the work spread over the wave slots comes to
+    // 195 us), so a block is split when its cost exceeds `ratio` x the group's mean work per wave slot (512 slots per
+    // XCD at 16 one-wave workgroups per CU): a whole small launch, the top few dozen blocks of a large one.
+    // split_mode < 0: ratio = -split_mode / 4 (default -5: 1.25).
+    const int mid[NCLASS] = {340, 300, 260, 220, 180, 136, 96, 68, 46, 28, 10, 0};
     long total = 0;
-    int heaviest = 0;
-    for (int c = NCLASS - 1; c >= 0; --c) {
-      total += (long)s_hist[c] * mid[c];
-      if (s_hist[c] > 0) heaviest = mid[c];
+    for (int c = 0; c < NCLASS; ++c) total += (long)s_hist[c] * mid[c];
+    int max_class = -1;                      // split the classes 0 .. max_class
+    if (ws.split_slots > 0) {
+      if (g_split_dev > 0) max_class = SPLIT_MAX_CLASS;
+      else if (g_split_dev < 0)
+        for (int c = 0; c <= SPLIT_MAX_CLASS; ++c)
+          if (4L * mid[c] * 512 > (long)(-g_split_dev) * total) max_class = c;
     }
-    const bool on = g_split_dev < 0 ? 2L * heaviest * 384 > (long)(-g_split_dev) * total : g_split_dev > 0;   // -3: ratio 1.5
-    s_split = (ws.split_slots > 0 && on) ? 1 : 0;
+    s_split = max_class;
   }
   __syncthreads();
-  const int split_slots = s_split ? ws.split_slots : 0;
+  const int split_slots = ws.split_slots, split_class = s_split;
   // pass 2: scatter (order inside a class is arbitrary: results never depend on it)
   int off[NCLASS];
 #pragma unroll
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
         const unsigned long long m = __ballot(cls == c);
         if (cls == c) {
           const int pos = off[c] + __popcll(m & lt);
-          ord[pos] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0) | ((c <= SPLIT_MAX_CLASS && pos < split_slots) ? ENTRY_SPLIT : 0);
+          ord[pos] = e | (c == NCLASS - 1 ? ENTRY_EMPTY : 0) | ((c <= split_class && pos < split_slots) ? ENTRY_SPLIT : 0);
         }
         off[c] += __popcll(m);
       }
@@ -501,8 +501,11 @@ struct Cand {
   float4 box, a, b;
   float2 c;      // (z2, denom = area + kEps)
   float rden;    // refined 1 / denom (k_setup's, the very operations the per-pixel code used to repeat)
-  int fid, idx;
+  int fid, idx;  // idx: list position (the ACFM_EDGE_CONST walk reads L.e0 / L.e1[idx] when it reaches the distance stage)
 };
+
+template <class LT, class = void> struct has_edge_const : std::false_type {};
+template <class LT> struct has_edge_const<LT, std::void_t<decltype(std::declval<LT&>().e0)>> : std::true_type {};
 
 template <class LT>
 __device__ __forceinline__ Cand load_cand(const LT& L, int i) {
@@ -554,7 +557,7 @@ __device__ __forceinline__ unsigned edge_cull4(const float4 a, const float4 b, f
 // were measured slower with it (+7 %, +2 %).
 template <bool EDGE_CULL, class LT, class Body>
 __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_n, float blur,
-                                          unsigned short* wl /* [RCAP], EDGE_CULL only */,
+                                          unsigned char* wl /* [2 CAP], EDGE_CULL only */,
                                           Body&& body) {
   const int by = (t.yi & ~7), bx = (t.xi & ~7);
   const int grp = t.lane >> 4;
@@ -601,7 +604,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
         hit = !((xi1 > b.y) | (xa0 < b.x) | (yi1 > b.w) | (ya0 < b.z));
       }
       const unsigned long long bw = __ballot(hit);
-      if (hit) wl[nw + __popcll(bw & lt)] = (unsigned short)c;
+      if (hit) wl[nw + __popcll(bw & lt)] = (unsigned char)c;
       nw += __popcll(bw);
     }
     if (nw == 0) return;
@@ -626,13 +629,13 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
       const float sc = 8.0f / fmaxf(zhi - zlo, 1e-12f);
       const int b0 = i0 < nw ? min(7, (int)((z0 - zlo) * sc)) : -1;
       const int b1 = i1 < nw ? min(7, (int)((z1 - zlo) * sc)) : -1;
-      unsigned short* wl2 = wl + LT::CAP;
+      unsigned char* wl2 = wl + LT::CAP;
       int base = 0;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const unsigned long long m0 = __ballot(b0 == c), m1 = __ballot(b1 == c);
-        if (b0 == c) wl2[base + __popcll(m0 & lt)] = (unsigned short)c0;
-        if (b1 == c) wl2[base + __popcll(m0) + __popcll(m1 & lt)] = (unsigned short)c1;
+        if (b0 == c) wl2[base + __popcll(m0 & lt)] = (unsigned char)c0;
+        if (b1 == c) wl2[base + __popcll(m0) + __popcll(m1 & lt)] = (unsigned char)c1;
         base += __popcll(m0) + __popcll(m1);
       }
       wl = wl2;
@@ -678,9 +681,26 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   // first) record: harmless, the lanes are masked by `have`.  (Prefetching the next record one
   // iteration ahead was measured: +16 VGPRs, no change in time.)
   const int last = max(my_n - 1, 0);
+#ifndef ACFM_WALK_PREFETCH
+#define ACFM_WALK_PREFETCH 1
+#endif
+#if ACFM_WALK_PREFETCH
+  // the list position of the NEXT iteration's candidate is read one iteration ahead: the walk's dependent chain per
+  // iteration is then one LDS round trip (the record) instead of two (sub-list byte -> record)
+  int nxt = my_n > 0 ? (split ? grp : (int)sub[0]) : 0;
+#endif
   for (int i = 0; i < n_max; ++i) {
+#if ACFM_WALK_PREFETCH
+    const int ci = nxt;
+    {
+      const int l2 = min(i + 1, last);
+      nxt = my_n > 0 ? (split ? 4 * l2 + grp : (int)sub[l2]) : 0;
+    }
+    const Cand cur = load_cand(L, ci);
+#else
     const int li = min(i, last);
     const Cand cur = load_cand(L, my_n > 0 ? (split ? 4 * li + grp : (int)sub[li]) : 0);
+#endif
     const bool have = i < my_n;
     const bool in_box = have &&
         !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
@@ -791,6 +811,9 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
         L.b[pos] = ws.rec[o].b;
         const float4 c4 = ws.rec[o].c;
         L.c[pos] = make_float4(c4.x, c4.z, c4.w, __int_as_float(f));
+#if ACFM_EDGE_CONST
+        if constexpr (has_edge_const<LT>::value) { L.e0[pos] = ws.rec[o].e0; L.e1[pos] = ws.rec[o].e1; }
+#endif
       }
       list_n += __popcll(bal);
     }
@@ -860,6 +883,39 @@ __device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4&
   h.d02 = d2.y;
   h.d12 = point_line_dist(xf, yf, x1, y1, x2, y2, tpar ? tpar + 2 : nullptr);
   if (tpar) { tpar[0] = t2.x; tpar[1] = t2.y; }
+  const float d = fminf(fminf(h.d01, h.d02), h.d12);
+  h.sd = inside ? -d : d;
+  return inside || !(d >= blur);
+}
+
+// The same with the per-edge constants of the candidate (ACFM_EDGE_CONST): E0 = (|e01|^2, |e02|^2, r01, r02),
+// E1 = (|e12|^2, r12, degenerate flag, -).  Operation for operation point_line_dist / point_line_dist2 minus what does
+// not depend on the pixel; a face with a degenerate edge (flag) must take test_face_dist (its distance-to-endpoint branch).
+__device__ __forceinline__ bool test_face_dist_e(float xf, float yf, const float4& A, const float4& B, const float4& E0,
+                                                 const float4& E1, float blur, bool inside, Hit& h) {
+  const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
+  {
+    const v2f ax = {x0, x0}, ay = {y0, y0}, bx = {A.z, A.w}, by = {B.x, B.y};
+    const v2f l2 = {E0.x, E0.y}, r = {E0.z, E0.w};
+    const v2f bax = bx - ax, bay = by - ay;
+    const v2f num = bax * (xf - ax) + bay * (yf - ay);
+    v2f t = num * r;
+    t = fma2(fma2(-l2, t, num), r, t);
+    t = fma2(fma2(-l2, t, num), r, t);
+    t.x = fminf(fmaxf(t.x, 0.0f), 1.0f); t.y = fminf(fmaxf(t.y, 0.0f), 1.0f);
+    const v2f qx = ax + t * bax, qy = ay + t * bay;
+    const v2f dx = qx - xf, dy = qy - yf;
+    const v2f d = dx * dx + dy * dy;
+    h.d01 = d.x; h.d02 = d.y;
+  }
+  {
+    const float bax = x2 - x1, bay = y2 - y1;
+    float t = div_by(bax * (xf - x1) + bay * (yf - y1), E1.x, E1.y);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float qx = x1 + t * bax, qy = y1 + t * bay;
+    const float dx = qx - xf, dy = qy - yf;
+    h.d12 = dx * dx + dy * dy;
+  }
   const float d = fminf(fminf(h.d01, h.d02), h.d12);
   h.sd = inside ? -d : d;
   return inside || !(d >= blur);
@@ -971,6 +1027,15 @@ struct FwdOut {
   // workspace over reads it (cover_in) instead of walking the faces
   int* cover_out;
   const int* cover_in;
+  // acfm_sil_forward_prefill: the K-nearest forward also stores the CONSTANT outputs of the texture render that will
+  // take this workspace over (acfm_tex_forward ws_ready = 3) on the blocks no face comes near -- the same blocks that
+  // render would fill (one emptiness rule: the cost counts of this workspace); here the stores drain behind the walk
+  // of the blocks with work, there they were 24 of the kernel's 36 us.  float storage only.
+  float* pf_imgs;            // [N,3,H,H] -> 0
+  float* pf_sil;             // [N,H,H] -> 0
+  int64_t* pf_p2f;           // [N,H,H,1] -> -1
+  int32_t* pf_tidx;          // [N,H,H] -> -1
+  int prefilled;             // texture forward from the cover plane: the empty blocks hold their constants already
 };
 
 __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& out, int n, int F, int f) {
@@ -979,16 +1044,63 @@ __device__ __forceinline__ void mark_visible(const RasterWs& ws, const FwdOut& o
   v[vi.x] = 1; v[vi.y] = 1; v[vi.z] = 1;
 }
 
-// Bubble-through insertion of (x, xq) into the sorted register list, four slots at a time.
+// Insertion of (x, xq) into the sorted register list, four slots at a time.
 // `lim` (wave-uniform) bounds the number of faces any lane of the wave can hold so far: slots
-// at or beyond it are still empty in every lane, so those compare-exchanges are skipped with
-// scalar branches while every register index stays a compile-time constant.
+// at or beyond it are still empty in every lane, so blocks that lie wholly beyond it are skipped
+// with scalar branches while every register index stays a compile-time constant.
+//
+// ACFM_INSERT_SHIFT = 1 (shipping): SHIFT form, top block first.  With P_k = (x < key[k]) the new list is
+//   key'[k] = P_k ? (P_{k-1} ? key[k-1] : x) : key[k]        (P_{-1} = false; sorted list: P_{k-1} implies P_k)
+// evaluated for k descending, in place: slot k reads only the OLD slots k and k-1 and x itself never changes.
+// Per slot one 64-bit compare + six selects, like the compare-exchange of the bubble form (0), but
+//   * no register copies: the bubble form carries the displaced element from slot to slot, and the compiler kept the
+//     old and the new 64-bit key of a slot in different register pairs (their 32-bit halves overlap in time), which
+//     cost 4 v_mov_b64 + 4 v_mov_b32 per 4-slot block -- a fifth of the insertion's instructions;
+//   * the compares of a block are independent of its selects (no v_cmp -> s_nop -> v_cndmask chains);
+//   * the walk is top-down, so the first block no lane's element enters ENDS the insertion (everything below holds
+//     smaller keys): the bubble form tested every block below the insertion point one by one.
+// Lanes that do not insert are masked by exec (their compare bits are 0).  Results are identical: both forms
+// produce THE sorted list of the K smallest keys (keys are unique per pixel: the face id is part of the key).
 #ifndef ACFM_ASM_SLOT
 #define ACFM_ASM_SLOT 1
 #endif
+#ifndef ACFM_INSERT_SHIFT
+#define ACFM_INSERT_SHIFT 1
+#endif
+__device__ __forceinline__ unsigned long long key_lt_mask(unsigned long long x, unsigned long long k) {
+  return __builtin_amdgcn_uicmpl(x, k, 36 /* ICMP_ULT */);   // one v_cmp_lt_u64 into an SGPR pair (lanes off: 0)
+}
+template <int K, int B>   // block B = slots [4B, min(4B + 4, K)), called for B = top .. 0
+__device__ __forceinline__ void shift_insert_block(unsigned long long (&key)[K], float (&q)[K], const unsigned long long x,
+                                                   const float xq, int lim) {
+  constexpr int LO = 4 * B, HI = (LO + 4 < K ? LO + 4 : K);
+  if (lim > LO) {   // (the list holds at most lim entries after this insertion: slots >= lim stay empty in every lane)
+    DIAG_ADD(9, 1);
+    unsigned long long pk = key_lt_mask(x, key[HI - 1]);
+    if (pk == 0ull) return;            // no lane's element enters this block, hence none enters a lower one
+    DIAG_ADD(8, 1);
+#pragma unroll
+    for (int k = HI - 1; k >= LO; --k) {
+      const unsigned long long pm = k > 0 ? key_lt_mask(x, key[k > 0 ? k - 1 : 0]) : 0ull;
+      const bool below = __builtin_amdgcn_inverse_ballot_w64(pm);   // the element goes below slot k: slot k takes k-1's
+      const bool here = __builtin_amdgcn_inverse_ballot_w64(pk);    // slot k changes at all
+      const unsigned long long sk = below ? key[k > 0 ? k - 1 : 0] : x;
+      const float sq = below ? q[k > 0 ? k - 1 : 0] : xq;
+      key[k] = here ? sk : key[k];
+      q[k] = here ? sq : q[k];
+      pk = pm;
+    }
+  }
+  if constexpr (B > 0) shift_insert_block<K, B - 1>(key, q, x, xq, lim);
+}
+
 template <int K, int LO>
 __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], float (&q)[K],
                                               unsigned long long& x, float& xq, int lim) {
+#if ACFM_INSERT_SHIFT
+  static_assert(LO == 0, "the shift form inserts into the whole list");
+  shift_insert_block<K, (K - 1) / 4>(key, q, x, xq, lim);
+#else
   // The list is sorted, so key[HI-1] is the largest of the block: if no active lane's element is
   // smaller, nothing moves in these four slots (the new face lies deeper than all of them in every
   // lane -- faces arrive in id order, not in depth order) and the block costs one compare.
@@ -1020,294 +1132,49 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
   if constexpr (LO + 4 < K) {
     if (lim > LO + 4) bubble_insert<K, LO + 4>(key, q, x, xq, lim);
   }
+#endif
 }
 
 // LDS of a forward workgroup (one wave).  The nearest-face kernels keep a 64-slot candidate list
 // (5.5 KB: the register budget, not LDS, then bounds the waves per SIMD -- measured on the
 // backward: 13.8 KB -> 6.9 KB per wave = 292 -> 256 us); the K-nearest kernels are register-bound
-// at 3-4 waves per SIMD anyway and need 64 K 8 bytes to stage the block's face ids.
-// forward walk: 0 = 4x4-group sub-lists (walk_wave, the shipping kernels); 1 = per-pixel candidate lists
-// (pix_lists_walk): an experiment kept for reference -- correct (all parity tests and the sweep pass) but
-// slower: 359 vs 258 us on the 64-frame bird launch.  Every lane walks its own list, so a wave-iteration always
-// pays the whole body (nothing is ever skipped wave-wide), all 64 lanes insert different faces at different
-// list positions (nearly every 4-slot block of the sorted insertion executes, 270 vs ~140 ns per iteration),
-// and max-over-64-lanes of the list lengths (~25) is not much below max-over-4-groups (~30).
-#ifndef ACFM_FWD_V2
-#define ACFM_FWD_V2 0
+// at 4 waves per SIMD and get 10 240 B each (16 one-wave workgroups per CU): with every slot of pix_to_face stored
+// (k_out = K) that is exactly the staging area of the block's ids, a union with the lists.
+// (The per-pixel-list forward walk of round 2, ACFM_FWD_V2, lives in tools/variants/fwd_v2_per_pixel_lists.inc.)
+//
+// ACFM_EDGE_CONST (K-nearest kernels): a candidate carries, besides its record, what the exact per-pixel distance
+// test needs per EDGE and not per pixel -- |e|^2 and the refined reciprocal 1/|e|^2 of the three edges (operands of
+// the IEEE-exact division of point_line_dist) and a flag for an edge with |e|^2 <= kEps -- computed once per face by
+// k_setup with the very operations the walk used to repeat for every (pixel, face) pair: two more 16-byte LDS
+// entries per candidate (32 B), ~33 instruction slots fewer per walk iteration, bit-identical values.
+#ifndef ACFM_EDGE_CONST
+#define ACFM_EDGE_CONST 0
 #endif
-// LDS of the per-pixel-list forward walk: PCAP candidate records of 128 bytes (the whole FaceRec), one byte list
-// per pixel (slot-major: list[i][lane], so a wave reads its i-th entries from 64 consecutive bytes) and the face-id
-// list of the coarse tile, whose front doubles as the queue of ids that passed the block's box test.
-// Records are 7 x 16 B = 28 dwords apart (the box lives in its own array): in the main loop every lane reads ITS
-// candidate's record with ds_read_b128, 16 lanes per LDS cycle, bank = dword address mod 64 -- with a stride of 32
-// dwords all candidates would sit on two bank groups (measured: 16-way conflicts, the walk 1.6x slower than the
-// one it replaces); 28 = 4 x 7 spreads 16 consecutive candidates over all 16 four-bank groups, and lanes on the
-// same candidate broadcast.
-template <int PCAP>
-struct PixLds {
-  static constexpr int CAP = PCAP;
-  float4 rec[PCAP][7];           // a, b, c (c.y = face id), e01, e12, e02, sn
-  float4 box[PCAP];
-  unsigned char list[PCAP][64];
-  fl_t fl[FLCAP];
+#ifndef ACFM_FWD_CAP
+#define ACFM_FWD_CAP (ACFM_EDGE_CONST ? 88 : RCAP)   // 96 B x 88 + sub-lists + id list + cull lists = 10 208 B <= 10 240
+#endif
+template <int CAP_>
+struct CandListET : CandListT<CAP_> {
+  float4 e0[CAP_];   // (|e01|^2, 1/|e01|^2, |e02|^2, 1/|e02|^2)   -- the pair the packed pipe evaluates together
+  float4 e1[CAP_];   // (|e12|^2, 1/|e12|^2, degenerate flag, -)
 };
-constexpr int PCAP_SOFT = 48;   // 6144 + 3072 + 1024 = 10240 B = the K = 20 id staging area: 16 waves per CU
-constexpr int PCAP_HARD = 32;   // 4096 + 2048 + 1024 = 7168 B
-template <int CAP, int PCAP, int MIN_BYTES>
+template <int CAP, int MIN_BYTES, bool EDGE>
 struct FwdLdsT {
   struct Lists {
-    CandListT<CAP> L;
+    typename std::conditional<EDGE, CandListET<CAP>, CandListT<CAP>>::type L;
     fl_t fl[FLCAP];
-    unsigned short wl[2 * CAP];   // the wave's list of the edge cull, and the same in depth order
+    unsigned char wl[2 * CAP];   // the wave's list of the edge cull, and the same in depth order (list positions < CAP <= 256)
   };
   union {
-#if ACFM_FWD_V2
-    PixLds<PCAP> p;
-#else
     Lists s;
-#endif
     char stage[MIN_BYTES > 16 ? MIN_BYTES : 16];   // the block's K ids in image order (the lists are dead by then)
   };
 };
-template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? RCAP : 64), (K > 1 ? PCAP_SOFT : PCAP_HARD), (K > 1 ? 64 * K * 8 : 0)>;
+template <int K> using FwdLdsK = FwdLdsT<(K > 1 ? ACFM_FWD_CAP : 64), (K > 1 ? 64 * K * 8 : 0), (K > 1 && ACFM_EDGE_CONST)>;
+#ifndef ACFM_NO_LDS_ASSERT
+static_assert(sizeof(FwdLdsK<20>) <= 10240, "the K = 20 forward runs 16 one-wave workgroups per CU: 10 240 B of LDS each");
+#endif
 
-#if ACFM_FWD_V2
-// ------------------------------------------------------------------------------- per-pixel lists
-// Exact per-pixel test on a candidate RECORD (FaceRec with its per-face constants).  Same operations in the
-// same order as test_face_depth / test_face_dist / the oracle for everything that depends on the pixel; what
-// depends on the face alone (edge vectors, squared lengths, refined reciprocals) comes from the record.
-//   edge_fn(p; v1, v2) = (px - x1)(y2 - y1) - (py - y1)(x2 - x1)                      = dx1 e12.y - dy1 e12.x
-//   edge_fn(p; v2, v0) = (px - x2)(y0 - y2) - (py - y2)(x0 - x2) = -(dx2 e02.y) + dy2 e02.x  (negations are exact)
-//   edge_fn(p; v0, v1) = (px - x0)(y1 - y0) - (py - y0)(x1 - x0)                      = dx0 e01.y - dy0 e01.x
-struct PixD { float dx0, dy0, dx1, dy1, dx2, dy2; };
-__device__ __forceinline__ PixD pix_deltas(float px, float py, const float4& a, const float4& b) {
-  PixD d;
-  d.dx0 = px - a.x; d.dy0 = py - a.y; d.dx1 = px - a.z; d.dy1 = py - b.x; d.dx2 = px - a.w; d.dy2 = py - b.y;
-  return d;
-}
-template <bool CLIP, bool INSIDE_ONLY = false>
-__device__ __forceinline__ bool rec_depth(const PixD& d, const float4& b, const float4& c, const float4& e01,
-                                          const float4& e12, const float4& e02, Hit& h, bool& inside) {
-  const float n0 = d.dx1 * e12.y - d.dy1 * e12.x;
-  const float n1 = d.dy2 * e02.x - d.dx2 * e02.y;
-  const float n2 = d.dx0 * e01.y - d.dy0 * e01.x;
-  const float denom = c.z, r = c.w;
-  const float w0 = div_by(n0, denom, r), w1 = div_by(n1, denom, r), w2 = div_by(n2, denom, r);
-  float c0 = w0, c1 = w1, c2 = w2;
-  inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
-  if (INSIDE_ONLY && !inside) return false;
-  if (CLIP) {
-    c0 = fmaxf(fminf(w0, 1.0f), 0.0f);
-    c1 = fmaxf(fminf(w1, 1.0f), 0.0f);
-    c2 = fmaxf(fminf(w2, 1.0f), 0.0f);
-    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-    const float rs = recip_refined(s);
-    c0 = div_by(c0, s, rs); c1 = div_by(c1, s, rs); c2 = div_by(c2, s, rs);
-  }
-  const float pz = c0 * b.z + c1 * b.w + c2 * c.x;
-  h.pz = pz; h.c0 = c0; h.c1 = c1; h.c2 = c2;
-  return !(pz < 0.0f);
-}
-// squared distance to the segment a + t e, (dxa, dya) = p - a; e = (ex, ey, |e|^2, refined 1/|e|^2), |e|^2 > kEps
-__device__ __forceinline__ float rec_seg_dist(float px, float py, float ax, float ay, float dxa, float dya, const float4& e) {
-  float t = div_by(e.x * dxa + e.y * dya, e.z, e.w);
-  t = fminf(fmaxf(t, 0.0f), 1.0f);
-  const float qx = ax + t * e.x, qy = ay + t * e.y;
-  const float dx = qx - px, dy = qy - py;
-  return dx * dx + dy * dy;
-}
-__device__ __forceinline__ bool rec_dist(float px, float py, const PixD& d, const float4& a, const float4& b,
-                                         const float4& e01, const float4& e12, const float4& e02, bool degenerate,
-                                         float blur, bool inside, Hit& h) {
-  if (degenerate) {   // an edge with |e|^2 <= kEps (rare): the unfactored evaluation with its distance-to-endpoint branch
-    h.d01 = point_line_dist(px, py, a.x, a.y, a.z, b.x);
-    h.d02 = point_line_dist(px, py, a.x, a.y, a.w, b.y);
-    h.d12 = point_line_dist(px, py, a.z, b.x, a.w, b.y);
-  } else {
-    h.d01 = rec_seg_dist(px, py, a.x, a.y, d.dx0, d.dy0, e01);
-    h.d02 = rec_seg_dist(px, py, a.x, a.y, d.dx0, d.dy0, e02);
-    h.d12 = rec_seg_dist(px, py, a.z, b.x, d.dx1, d.dy1, e12);
-  }
-  const float dm = fminf(fminf(h.d01, h.d02), h.d12);
-  h.sd = inside ? -dm : dm;
-  return inside || !(dm >= blur);
-}
-
-// Forward walk with PER-PIXEL candidate lists.  The block's faces are binned exactly as in bin_and_walk (coarse-tile
-// bitmask -> id list -> box test against the 8x8 block, 64 ids per round), but the ids that pass are queued and
-// handled in chunks of CAP: (1) CAP lanes copy the chunk's 128-byte records into LDS; (2) [ORDER] the chunk is dealt
-// into 8 depth classes so that lists fill roughly front to back; (3) PREFILTER, lane = pixel, one candidate per
-// iteration for the whole wave (uniform LDS reads): the three edge functions of the pixel -- the exact test's own
-// operations -- scaled to line distances say whether the pixel can possibly be accepted (blur == 0: inside <=> all
-// three have the sign of the area; blur > 0: no edge line farther than sqrt(blur) (+ slack) outside, and inside the
-// blur-expanded box); a pixel that can is given the candidate's index in ITS list; (4) MAIN loop, lane = pixel,
-// every lane walks its own list: the exact test runs only on (pixel, face) pairs that are almost surely accepted,
-// each lane on a different face.  Against the 4x4-group walk (walk_wave: ~25 faces per group for 13 kept per pixel,
-// a wave-iteration as long as one lane survives) the wave runs max-over-lanes(list length) iterations of the
-// expensive body instead of max-over-groups(faces met), and nothing of it is spent on pairs the prefilter rejects.
-// The prefilter is conservative: it never rejects a pair the exact test accepts (slack 1e-3 sqrt(blur), four orders
-// above the rounding of an edge function), so results are unchanged -- the lists only decide what is looked at.
-// Split role (t.sub >= 0: 16 pixels x 4 quarter-waves): quarter s takes the candidates j = s (mod 4) of the chunk.
-// body(have, c) is called for every lane of the wave: `have` = the lane has an entry this iteration, c = its
-// candidate's index into P.rec.
-template <bool INSIDE_PREFILTER, bool ORDER, int CAP, class Body>
-__device__ __forceinline__ void pix_lists_walk(const RasterWs& ws, const Tile& t, int F, int H, float blur,
-                                               float box_shrink, PixLds<CAP>& P, Body&& body) {
-  if (t.empty) return;  // flagged by k_order: no face box near this block
-  float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
-#pragma unroll
-  for (int i = 1; i < SETUP_SLICES; ++i) {
-    const float4 m2 = ws.mbox[(size_t)t.n * SETUP_SLICES + i];
-    mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
-  }
-  if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
-  const unsigned long long lt = (1ull << t.lane) - 1ull;
-  const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
-  const int cty = (t.yi & ~7) / CTILE, ctx = (t.xi & ~7) / CTILE;
-  const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(ws.cmask) +
-                                   ((size_t)t.n * ctiles * ctiles + (size_t)cty * ctiles + ctx) * words;
-  fl_t* s_fl = P.fl;
-  const float r_cull = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sqrtf(blur) * 1.001f)));
-  const bool split = t.sub >= 0;
-  const int quarter = t.lane >> 4;
-
-  // one chunk of n <= CAP queued ids (s_fl[0 .. n)): records -> LDS, order, prefilter, main loop
-  auto chunk = [&](int n) {
-    if (t.lane < n) {
-      const int f = (int)s_fl[t.lane];
-      const float4* g = reinterpret_cast<const float4*>(&ws.rec[(size_t)t.n * F + f]);
-      float4 r0 = g[0], r1 = g[1], r2 = g[2], r3 = g[3], r4 = g[4], r5 = g[5], r6 = g[6], r7 = g[7];
-      r0.x += box_shrink; r0.y -= box_shrink; r0.z += box_shrink; r0.w -= box_shrink;
-      r3.y = __int_as_float(f);                  // (area itself is not used by the record path: denom and its reciprocal are)
-      float4* o = P.rec[t.lane];
-      P.box[t.lane] = r0;
-      o[0] = r1; o[1] = r2; o[2] = r3; o[3] = r4; o[4] = r5; o[5] = r6; o[6] = r7;
-    }
-    wave_lds_sync();
-    int ordreg = t.lane;                          // lane j: the candidate visited j-th
-    if (ORDER && n > 8) {
-      // front to back, roughly: 8 depth classes by the face's nearest vertex (counting sort with ballots); the order
-      // never changes a result, it changes how far a new face has to travel in the sorted per-pixel lists
-      const float INF = __builtin_inff();
-      const bool live = t.lane < n;
-      const float z = live ? min3f(P.rec[t.lane][1].z, P.rec[t.lane][1].w, P.rec[t.lane][2].x) : INF;
-      const float zlo = wave_min(z), zhi = wave_max(live ? z : -INF);
-      const float sc = 8.0f / fmaxf(zhi - zlo, 1e-12f);
-      const int cls = live ? min(7, (int)((z - zlo) * sc)) : 8;
-      int base = 0, pos = 0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (cls == c) pos = base + __popcll(m & lt);
-        base += __popcll(m);
-      }
-      unsigned char* tmp = &P.list[0][0];         // (free until the prefilter fills it)
-      if (live) tmp[pos] = (unsigned char)t.lane;
-      wave_lds_sync();
-      ordreg = live ? (int)tmp[t.lane] : 0;
-      wave_lds_sync();
-    }
-    // prefilter: lane = pixel, candidates one by one
-    int cnt = 0;
-    unsigned char* mylist = &P.list[0][t.lane];
-#pragma unroll 1
-    for (int j = 0; j < n; ++j) {
-      const int c = __builtin_amdgcn_readlane(ordreg, j);
-      const float4* R = P.rec[c];
-      const float4 a = R[0], b = R[1];
-      const float4 e01 = R[3], e12 = R[4], e02 = R[5], sn = R[6];
-      const PixD d = pix_deltas(t.xf, t.yf, a, b);
-      const float n0 = d.dx1 * e12.y - d.dy1 * e12.x;
-      const float n1 = d.dy2 * e02.x - d.dx2 * e02.y;
-      const float n2 = d.dx0 * e01.y - d.dy0 * e01.x;
-      // signed distances to the three edge LINES, positive outside (edge function x (-sign(area) / |edge|))
-      const float o = max3f(n0 * sn.y, n1 * sn.z, n2 * sn.x);
-      bool keep;
-      if (INSIDE_PREFILTER) {
-        keep = !(o > 0.0f);                       // inside <=> every edge function has the sign of the area (o < 0)
-      } else {
-        const float4 box = P.box[c];
-        keep = !(o > r_cull) && !((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z));
-      }
-      keep = keep && t.valid && (!split || (j & 3) == quarter);
-      if (keep) mylist[cnt * 64] = (unsigned char)c;
-      cnt += keep ? 1 : 0;
-    }
-    wave_lds_sync();
-    int maxlen = cnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-#pragma unroll 1
-    for (int i = 0; i < maxlen; ++i) {
-      const bool have = i < cnt;
-      const int c = have ? (int)mylist[i * 64] : 0;
-      body(have, c);
-    }
-    wave_lds_sync();
-  };
-
-  // One loop with a single chunk() site (its body holds the per-pixel top-K lists in registers: a second inlined
-  // copy costs registers).  State: the id list s_fl[i0 .. total) still to be tested (or the direct range
-  // [f0, fe)), and the queue of ids that passed, s_fl[0 .. pend_n), which never reaches past the read position
-  // (a round reads 64 ids into registers before it appends at most 64).
-  int pend_n = 0;
-  int w0 = -64, total = 0, i0 = 0, f0 = 0, fe = 0;
-  bool direct = false;
-#pragma unroll 1
-  for (;;) {
-    const bool exhausted = !(direct ? f0 < fe : i0 < total);
-    if (pend_n >= CAP || (exhausted && pend_n > 0)) {
-      const int n = min(pend_n, CAP);
-      chunk(n);
-      const int rest = pend_n - n;                // < 64: a round adds at most 64 to a queue shorter than CAP
-      const fl_t v = t.lane < rest ? s_fl[n + t.lane] : (fl_t)0;
-      wave_lds_sync();
-      if (t.lane < rest) s_fl[t.lane] = v;
-      wave_lds_sync();
-      pend_n = rest;
-      continue;
-    }
-    if (exhausted) {                              // (the queue is empty here) next 4096 faces of the coarse tile's mask
-      w0 += 64;
-      if (w0 >= words) break;
-      unsigned long long m = (w0 + t.lane < words) ? mrow[w0 + t.lane] : 0ull;
-      const int cnt = __popcll(m);
-      const int incl = wave_inclusive_scan(cnt, t.lane);
-      total = __builtin_amdgcn_readlane(incl, 63);
-      i0 = 0;
-      direct = total > FLCAP;  // a coarse tile crowded beyond the id list: test these 4096 faces directly
-      if (direct) {
-        f0 = w0 * 64; fe = min(F, (w0 + 64) * 64); total = 0;
-      } else if (total > 0) {
-        int pos = incl - cnt;
-        const int fbase = (w0 + t.lane) * 64;
-#pragma unroll 1
-        while (m != 0ull) {
-          s_fl[pos++] = (fl_t)(fbase + (int)__ffsll((long long)m) - 1);
-          m &= m - 1ull;
-        }
-        wave_lds_sync();
-      }
-      continue;
-    }
-    int f;
-    if (direct) { f = (f0 + t.lane < fe) ? f0 + t.lane : -1; f0 += RT; }
-    else { f = (i0 + t.lane < total) ? (int)s_fl[i0 + t.lane] : -1; i0 += RT; }
-    bool pass = false;
-    if (f >= 0) {
-      float4 b = ws.rec[(size_t)t.n * F + f].box;
-      b.x += box_shrink; b.y -= box_shrink; b.z += box_shrink; b.w -= box_shrink;
-      pass = !(t.t_xmin > b.y || t.t_xmax < b.x || t.t_ymin > b.w || t.t_ymax < b.z);
-    }
-    const unsigned long long bal = __ballot(pass);
-    if (pass) s_fl[pend_n + __popcll(bal & lt)] = (fl_t)f;
-    pend_n += __popcll(bal);
-    wave_lds_sync();
-  }
-}
-
-#endif  // ACFM_FWD_V2
 
 // Constant outputs of a flagged-empty 8x8 block (no face box comes near it): exactly what
 // fwd_block leaves for a block without candidates.  Lane i owns pixel (i / 8, i % 8) of the block;
@@ -1348,6 +1215,11 @@ __device__ __forceinline__ void fwd_fill_block(const FwdOut& out, int n, int by,
       // (kth is left alone: the backward reads it only where mask != 0, and mask is 0 on this whole block)
       st_real(out.mask, pix, 0.0f, out.h16);
       if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
+      if (out.pf_imgs) {
+        const size_t HW = (size_t)H * H, io = (size_t)n * 3 * HW + (size_t)yi * H + xi;
+        out.pf_imgs[io] = 0.f; out.pf_imgs[io + HW] = 0.f; out.pf_imgs[io + 2 * HW] = 0.f;
+        out.pf_sil[pix] = 0.f; out.pf_tidx[pix] = -1; out.pf_p2f[pix] = -1;
+      }
     }
     if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
       const int tiles = (H + RBLK - 1) / RBLK;
@@ -1416,6 +1288,11 @@ __device__ __forceinline__ void fwd_fill_block_whole(const FwdOut& out, int n, i
   } else {
     st_real(out.mask, pix, 0.0f, out.h16);   // (kth: see fwd_fill_block)
     if (out.kout == 1) st_face(out.p2f, pix, -1, out.h16);
+    if (out.pf_imgs) {
+      const size_t HW = (size_t)H * H, io = pix + (size_t)n * 2 * HW;
+      out.pf_imgs[io] = 0.f; out.pf_imgs[io + HW] = 0.f; out.pf_imgs[io + 2 * HW] = 0.f;
+      out.pf_sil[pix] = 0.f; out.pf_tidx[pix] = -1; out.pf_p2f[pix] = -1;
+    }
     if (out.lpart && lane < 4) {   // mask = 0 on the whole block: nothing beyond the finish kernel's sum of gt
       const int tiles = H / RBLK;
       out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1520,10 +1397,8 @@ __device__ __forceinline__ void k1_finish(const RasterWs& ws, const Tile& t, int
 template <int K, bool CLIP, bool TEX>
 __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int F, int H, float blur, float sigma,
                                           const FwdOut& out, FwdLdsK<K>& S) {
-#if !ACFM_FWD_V2
   auto& L = S.s.L;
   fl_t* s_fl = S.s.fl;
-#endif
   const int n = t.n;
   const int64_t fbase = (int64_t)n * F;
 
@@ -1534,34 +1409,6 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     // so the three edge distances decide nothing; only the winner's signed distance is ever used
     // (the blend weight of the texture branch) and is evaluated once per pixel after the walk.
     const bool dist_late = !(blur > 0.0f);
-#if ACFM_FWD_V2
-    auto& P = S.p;
-    auto body1 = [&](bool have, int c, auto late) {
-      if (!have) return;
-      const float4* R = P.rec[c];
-      const float4 box = P.box[c], a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
-      // (the oracle's box test; with blur = 0 it is implied by `inside` up to rounding, and kept for that reason)
-      if ((t.xf > box.y) | (t.xf < box.x) | (t.yf > box.w) | (t.yf < box.z)) return;
-      const PixD d = pix_deltas(t.xf, t.yf, a, b);
-      Hit h;
-      h.sd = 0.f;
-      bool inside = false;
-      if (decltype(late)::value) {
-        if (!rec_depth<CLIP, true>(d, b, cc, e01, e12, e02, h, inside)) return;
-      } else {
-        if (!rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside)) return;
-        if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
-      }
-      const unsigned long long key = make_key(h.pz, __float_as_int(cc.y));
-      if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
-    };
-    if (dist_late)
-      pix_lists_walk<true, false>(ws, t, F, H, blur, out.box_shrink, P,
-                                  [&](bool have, int c) { body1(have, c, std::true_type()); });
-    else
-      pix_lists_walk<false, false>(ws, t, F, H, blur, out.box_shrink, P,
-                                   [&](bool have, int c) { body1(have, c, std::false_type()); });
-#else
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
         if (!(in_box && t.valid)) return;
@@ -1578,7 +1425,6 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
         if (key < bestkey) { bestkey = key; bestsd = h.sd; bestb0 = h.c0; bestb1 = h.c1; bestb2 = h.c2; }
       });
     });
-#endif
     k1_finish<CLIP, TEX>(ws, t, F, H, sigma, out, bestkey, bestsd, bestb0, bestb1, bestb2, dist_late);
   } else {
     // Per-pixel top-K list: K (depth|face) keys + their blend factors (1 - p), kept SORTED in
@@ -1592,28 +1438,7 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
     for (int k = 0; k < K; ++k) { key[k] = KEY_NONE; q[k] = 1.0f; }
     int seen = 0;  // faces walked so far by this wave (uniform): no lane holds more than that
     unsigned long long cbest = KEY_NONE;   // ACFM_RECORD_COVER: nearest covering face so far
-#if ACFM_FWD_V2
-    auto& P = S.p;
-    pix_lists_walk<false, true>(ws, t, F, H, blur, out.box_shrink, P, [&](bool have, int c) {
-      const float4* R = P.rec[c];
-      const float4 a = R[0], b = R[1], cc = R[2], e01 = R[3], e12 = R[4], e02 = R[5];
-      const PixD d = pix_deltas(t.xf, t.yf, a, b);
-      // stage 1 (depth): a face that is not nearer than the K-th kept face of a full list cannot enter it
-      // (empty slots hold ~0, so x < key[K-1] is always true for a list that is not full yet)
-      Hit h;
-      bool inside = false;
-      bool live = have && rec_depth<CLIP>(d, b, cc, e01, e12, e02, h, inside);
-      unsigned long long x = make_key(h.pz, __float_as_int(cc.y));
-      live = live && (x < key[K - 1]);
-      seen += 1;
-      if (__ballot(live) == 0ull) return;
-      if (!live) return;
-      if (!rec_dist(t.xf, t.yf, d, a, b, e01, e12, e02, R[6].w != 0.f, blur, inside, h)) return;
-      float xq = 1.0f - sigmoid_neg_fast(h.sd, sigma, sig_scale);
-      bubble_insert<K, 0>(key, q, x, xq, __builtin_amdgcn_readfirstlane(seen));
-    });
-#else
-    unsigned short* s_wl = S.s.wl;  // first stage of the edge cull
+    unsigned char* s_wl = S.s.wl;  // first stage of the edge cull
     DIAG_ADD(0, 1);
     bin_and_walk(ws, t, F, H, L, s_fl, out.box_shrink, [&](int list_n) {
       DIAG_ADD(1, 1); DIAG_ADD(2, list_n);
@@ -1658,7 +1483,17 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
 #ifdef ACFM_DIAG_NO_STAGE2
         h.sd = h.pz;
 #else
+#if ACFM_EDGE_CONST
+        // (read here, not with the record: 8 registers that need not live through the depth stage)
+        const float4 e1 = L.e1[cd.idx];
+        if (__ballot(e1.z != 0.0f) != 0ull) {   // (rare: some lane's face has an edge shorter than sqrt(kEps))
+          if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
+        } else {
+          if (!test_face_dist_e(t.xf, t.yf, cd.a, cd.b, L.e0[cd.idx], e1, blur, inside, h)) return;
+        }
+#else
         if (!test_face_dist(t.xf, t.yf, cd.a, cd.b, blur, inside, h)) return;
+#endif
 #endif
         DIAG_ADD(7, __popcll(__ballot(true))); DIAG_ADD(11, 1);
 #ifdef ACFM_DIAG_COUNT
@@ -1676,7 +1511,6 @@ __device__ __forceinline__ void fwd_block(const RasterWs& ws, const Tile& t, int
       });
       seen += list_n;
     });
-#endif
     const bool split = t.sub >= 0;
     if (split) {
       // The four 16-lane groups hold the K nearest of their quarter of the candidates for the same
@@ -1881,7 +1715,19 @@ __global__ __launch_bounds__(64 * COVER_WPB) void k_tex_cover(RasterWs ws, int N
   // waves at the high end render (below), so that no wave queues both.
   const bool quads = (H & 31) == 0 && !out.h16;
   int work_j0 = sc.j0;
-  if (quads) {
+  if (out.prefilled) {
+    // the silhouette render that left the cover plane stored these blocks' constants too (acfm_sil_forward_prefill);
+    // only the fused MSE's partial-sum records of the empty blocks remain
+    if (out.lpart) {
+      const int n_empty = sc.per - sc.n_work;
+      for (int e = sc.n_work + sc.j0 * 64 + lane; e < sc.per; e += sc.stride * 64) {
+        int n, by, bx;
+        entry_block(ws.order[(size_t)sc.g * sc.per + e], sc, H, n, by, bx);
+        out.lpart[(((size_t)n * tiles + by / RBLK) * tiles + bx / RBLK) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      (void)n_empty;
+    }
+  } else if (quads) {
     const FillLane<1> fl = make_fill_lane<1>(H, lane);
     const int qrow = tiles / 4, units = (N / sc.G) * tiles * qrow;
     const size_t HW = (size_t)H * H;
@@ -2775,7 +2621,9 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
                             int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
                             void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
                             size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream, bool fused,
-                            const void* gt, const void* edt, int ref_batch, float* losses) {
+                            const void* gt, const void* edt, int ref_batch, float* losses,
+                            float* pf_imgs = nullptr, float* pf_sil = nullptr, int64_t* pf_p2f = nullptr,
+                            int32_t* pf_tidx = nullptr) {
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (fused && (!losses || ref_batch <= 0 || N % ref_batch != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
@@ -2801,6 +2649,10 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.sig_scale = 1.44269504088896341f / sigma;
   out.lrb = 1;
   if (tn.cover) out.cover_out = ws.cover;
+  if (pf_imgs) {   // all four or none; only with the cover plane (the texture render it prepares shades from it) and float storage
+    if (!pf_sil || !pf_p2f || !pf_tidx || !tn.cover || tn.f16) return ACFM_E_BADARG;
+    out.pf_imgs = pf_imgs; out.pf_sil = pf_sil; out.pf_p2f = pf_p2f; out.pf_tidx = pf_tidx;
+  }
   if (fused) { out.lgt = gt; out.ledt = edt; out.lrb = ref_batch; out.lpart = ws.lpart; }
   switch (K) {
     case 20: rc = launch_sil_fwd<20>(ws, N, F, H, blur_radius, sigma, out, tn, st); break;
@@ -2828,6 +2680,17 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
                      size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream) {
   return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
                           pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr);
+}
+
+int acfm_sil_forward_prefill(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
+                             int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
+                             void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                             size_t ws_bytes, const AcfmRasterTuning* tuning, float* tex_imgs, float* tex_sil,
+                             int64_t* tex_pix_to_face, int32_t* tex_texel_idx, void* stream) {
+  if (!tex_imgs || !tex_sil || !tex_pix_to_face || !tex_texel_idx) return ACFM_E_BADARG;
+  return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
+                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr,
+                          tex_imgs, tex_sil, tex_pix_to_face, tex_texel_idx);
 }
 
 int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* gt,
@@ -2960,9 +2823,14 @@ static int tex_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.h16 = tn.f16 ? 1 : 0;
   out.box_shrink = ws_ready ? sqrtf(ws_blur) * (1.0f - 1e-5f) : 0.f;
   out.lrb = 1;
-  if (ws_ready == 2) {
+  if (ws_ready < 0 || ws_ready > 3) return ACFM_E_BADARG;
+  if (ws_ready >= 2) {
     if (!tn.cover) return ACFM_E_BADARG;   // the tuning of the render that filled the workspace says whether the plane is there
     out.cover_in = ws.cover;
+    if (ws_ready == 3) {                   // ... and that render (acfm_sil_forward_prefill) stored the empty blocks' constants
+      if (tn.f16) return ACFM_E_BADARG;
+      out.prefilled = 1;
+    }
   }
   if (loss) {
     if (!ref_img || !ref_mask || ref_batch <= 0 || N % ref_batch != 0) return ACFM_E_BADARG;

@@ -127,6 +127,9 @@ def _setup_key(v, c, f, H, offset_z):
             _capture_id(v.device), _EPOCH[0])
 
 
+PREFILL_TEX = [True]    # the silhouette render pre-fills the following texture render's empty blocks (see _SilRender.forward)
+
+
 # ACFM_RECORD_COVER: the silhouette render can note the nearest COVERING face of every pixel on its way (a few
 # instructions per covering pair), and the texture render that takes its workspace over then shades from that plane
 # instead of binning and walking the faces again (70 -> ~30 us per 64 frames @256^2).  Worth it only when a texture
@@ -156,19 +159,27 @@ def _cover_taken(device, tune):
     return 2 if (tune is not None and tune.flags & 4) else 1
 
 
-def _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune):
+def _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune, prefill=None):
     if _SHARE[0]:
-        ent = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune)
+        ent = (_setup_key(v, c, f, H, offset_z), ws, nb, float(blur), (v, c, f), tune, [prefill])
         with _LOCK:
             _SETUP[v.device] = ent
 
 
+def _take_prefill(holder, N, H):
+    """The texture-output buffers (imgs, sil, pix_to_face, texel_idx) that the silhouette render of a shared setup
+    pre-filled on the empty blocks -- handed out once -- or None."""
+    with _LOCK:
+        pf, holder[0] = holder[0], None
+    return pf if (pf is not None and tuple(pf[0].shape) == (N, 3, H, H)) else None
+
+
 def _shared_setup(v, c, f, H, offset_z):
-    """-> (ws, nbytes, blur, tuning) of a silhouette render of exactly these inputs, or None."""
+    """-> (ws, nbytes, blur, tuning, prefill holder) of a silhouette render of exactly these inputs, or None."""
     with _LOCK:
         ent = _SETUP.get(v.device) if _SHARE[0] else None
     if ent is not None and ent[0] == _setup_key(v, c, f, H, offset_z):
-        return ent[1], ent[2], ent[3], ent[5]
+        return ent[1], ent[2], ent[3], ent[5], ent[6]
     return None
 
 
@@ -875,12 +886,28 @@ class _SilRender(torch.autograd.Function):
         if f16:
             tune = _lib.with_f16(tune, True)
         tp = _lib.tuning_ptr(tune)
+        # a texture render of this prediction is expected (the cover flag is on while they do follow): its constant
+        # outputs on the empty blocks are stored by THIS kernel, behind the walk, into buffers that render then adopts
+        # (acfm_sil_forward_prefill / acfm_tex_forward ws_ready = 3: -20 us of the texture kernel's 36)
+        prefill = None
+        if PREFILL_TEX[0] and tune is not None and (tune.flags & 4) and not f16 and _SHARE[0]:
+            prefill = (torch.empty((N, 3, H, H), dtype=torch.float32, device=v.device),
+                       torch.empty((N, H, H), dtype=torch.float32, device=v.device),
+                       torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device),
+                       torch.empty((N, H, H), dtype=torch.int32, device=v.device))
         with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().acfm_sil_forward(
-                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
-                float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
-                _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)), "acfm_sil_forward")
-        _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune)
+            if prefill is not None:
+                _lib.check(_lib.lib().acfm_sil_forward_prefill(
+                    _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
+                    float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
+                    _lib.ptr(ws), nb, tp, _lib.ptr(prefill[0]), _lib.ptr(prefill[1]), _lib.ptr(prefill[2]),
+                    _lib.ptr(prefill[3]), _lib.cur_stream(v.device)), "acfm_sil_forward_prefill")
+            else:
+                _lib.check(_lib.lib().acfm_sil_forward(
+                    _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
+                    float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
+                    _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)), "acfm_sil_forward")
+        _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune, prefill)
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
         ctx.ws = (ws, nb, tune)  # face records + tile schedule: reused by backward (no second setup)
@@ -1058,17 +1085,23 @@ class _TexRender(torch.autograd.Function):
                              "N=%d F=%d" % (tuple(a.shape), N, F))
         R = a.shape[2]
         rdt = torch.float16 if f16 else torch.float32
-        imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
-        sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
-        p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
-        tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         shared = _shared_setup(v, c, f, H, offset_z)
+        holder = None
         if shared is not None:      # the workspace (and the tuning it was carved with) of the silhouette render
-            ws, nb, ws_blur, tune = shared
+            ws, nb, ws_blur, tune, holder = shared
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
         ws_ready = _cover_taken(v.device, tune) if shared is not None else 0
+        pf = _take_prefill(holder, N, H) if (ws_ready == 2 and not f16) else None
+        if pf is not None:
+            imgs, sil, p2f, tidx = pf          # their empty blocks were stored by the silhouette render
+            ws_ready = 3
+        else:
+            imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
+            sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
+            p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
+            tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_forward(
@@ -1152,18 +1185,24 @@ class _TexRenderMSE(torch.autograd.Function):
             raise ValueError("ref_img [N or N/G,3,H,H] and ref_mask [same batch,H,H]")
         rm = rm.reshape(RB, H, H)
         rdt = torch.float16 if f16 else torch.float32
-        imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
-        sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
-        p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
-        tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         loss = torch.empty((N,), dtype=torch.float32, device=v.device)
         shared = _shared_setup(v, c, f, H, offset_z)
+        holder = None
         if shared is not None:
-            ws, nb, ws_blur, tune = shared
+            ws, nb, ws_blur, tune, holder = shared
         else:
             ws, nb = _workspace(N, V, F, H, v.device)
             ws_blur, tune = 0.0, _lib.tuning()[1]
         ws_ready = _cover_taken(v.device, tune) if shared is not None else 0
+        pf = _take_prefill(holder, N, H) if (ws_ready == 2 and not f16) else None
+        if pf is not None:
+            imgs, sil, p2f, tidx = pf
+            ws_ready = 3
+        else:
+            imgs = torch.empty((N, 3, H, H), dtype=rdt, device=v.device)
+            sil = torch.empty((N, H, H), dtype=rdt, device=v.device)
+            p2f = torch.empty((N, H, H, 1), dtype=torch.int32 if f16 else torch.int64, device=v.device)
+            tidx = torch.empty((N, H, H), dtype=torch.int32, device=v.device)
         tune = _lib.with_f16(tune, f16)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().acfm_tex_mse_forward(

@@ -47,6 +47,86 @@ def refine_total(renderer, solver, delta, cam, faces, masks, edts_barrier, bound
     return total, pred_v
 
 
+class ClipRefiner:
+    """The refinement loop as an object: `step()` performs one Adam iteration (render, losses, backward, update);
+    `capture()` records one iteration into a hipGraph after `n_eager` eager ones (Adam's moment estimates exist, the
+    allocator is warm) and `step()` replays it from then on.  refine_clip() drives it; bench.py --config 3 times
+    `step()`.  State: `delta` [N,K_h,3] (handle offsets), `cam_raw` [N,7] (if the cameras are optimised), `history`."""
+
+    def __init__(self, renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
+                 optimize_camera=False, mask_loss_wt=1.0, boundaries_reg_wt=1.0, edt_reg_wt=0.1, bdt_reg_wt=0.1,
+                 of_loss_wt=0.0, optical_flows=None, of_renderer=None, num_frames=2, lr=5e-3, capturable=False,
+                 log_len=1):
+        self.args = (renderer, solver, faces, masks, edts_barrier, boundaries)
+        self.kw = (mask_loss_wt, boundaries_reg_wt, edt_reg_wt, bdt_reg_wt, of_loss_wt, optical_flows, of_renderer, num_frames)
+        self.delta = delta_v_res.clone().detach().requires_grad_(True)
+        params = [self.delta]
+        self.optimize_camera = optimize_camera
+        self.cam_raw = None
+        if optimize_camera:
+            # the reference optimises scale, trans and quat as three tensors (predictor.py:296-300); Adam is
+            # element-wise, so one [N,7] leaf is the same optimisation with a third of the launches
+            self.cam_raw = cam_pred.clone().detach().requires_grad_(True)
+            params.append(self.cam_raw)
+        self.capturable = bool(capturable and self.delta.is_cuda)
+        # one fused multi-tensor kernel per step instead of ~a dozen foreach launches (the loop is
+        # launch-latency-bound: ~30 short kernels of this library per iteration)
+        self.opt = torch.optim.Adam(params, lr=lr, capturable=self.capturable, fused=bool(self.delta.is_cuda))
+        self.cam_fixed = cam_pred.detach()
+        self.cam_out, self.pred_v = self.cam_fixed, None
+        self.hist_buf = torch.zeros(max(int(log_len), 1), device=self.delta.device)
+        self.it_idx = torch.zeros((), dtype=torch.long, device=self.delta.device)
+        self.graph = None
+        self.iterations = 0
+
+    def _iteration(self):
+        renderer, solver, faces, masks, edts_barrier, boundaries = self.args
+        cam = self.cam_fixed
+        if self.optimize_camera:
+            if self.cam_raw.is_cuda:
+                cam = ops.camera_normalize(self.cam_raw)
+            else:
+                cam = torch.cat([self.cam_raw[:, :3], torch.nn.functional.normalize(self.cam_raw[:, 3:], dim=-1)], dim=1)
+        total, pred_v = refine_total(renderer, solver, self.delta, cam, faces, masks, edts_barrier, boundaries, *self.kw)
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        self.opt.step()
+        self.hist_buf.index_put_((self.it_idx.clamp(max=self.hist_buf.numel() - 1),), total.detach())   # the loss log stays on the device
+        self.it_idx.add_(1)
+        self.cam_out, self.pred_v = cam.detach(), pred_v.detach()
+
+    def capture(self, n_eager=3):
+        """n_eager eager iterations on a side stream, then one iteration recorded (not executed) into a hipGraph."""
+        if not self.capturable:
+            raise RuntimeError("ClipRefiner(capturable=True) on device tensors is needed to capture the iteration")
+        dev = self.delta.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(n_eager):
+                self._iteration()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.iterations += n_eager
+        self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._iteration()
+        return n_eager
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._iteration()
+        self.iterations += 1
+
+    def history(self):
+        n = min(self.iterations, self.hist_buf.numel())
+        if self.graph is not None:
+            ops.invalidate_setups()          # the replays rewrote the loop's tensors without version bumps
+        return self.hist_buf[:n].tolist()
+
+
 def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
                 num_optim_iter=20, optimize_camera=False, mask_loss_wt=1.0, boundaries_reg_wt=1.0,
                 edt_reg_wt=0.1, bdt_reg_wt=0.1, of_loss_wt=0.0, optical_flows=None, of_renderer=None,
@@ -58,58 +138,16 @@ def refine_clip(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barr
     (~30 short kernels per iteration) and every entry point is stream-ordered, so the replayed
     iterations perform exactly the eager sequence of updates without returning to Python.
     Returns (pred_v, cam, delta, history of total losses)."""
-    delta = delta_v_res.clone().detach().requires_grad_(True)
-    params = [delta]
-    if optimize_camera:
-        # the reference optimises scale, trans and quat as three tensors (predictor.py:296-300); Adam is
-        # element-wise, so one [N,7] leaf is the same optimisation with a third of the launches
-        cam_raw = cam_pred.clone().detach().requires_grad_(True)
-        params.append(cam_raw)
-    graphable = use_graph and delta.is_cuda
-    # one fused multi-tensor kernel per step instead of ~a dozen foreach launches (the loop is
-    # launch-latency-bound: ~30 short kernels of this library per iteration)
-    opt = torch.optim.Adam(params, lr=lr, capturable=graphable, fused=bool(delta.is_cuda))
-    state = {"cam": cam_pred.detach(), "pred_v": None}
-    hist_buf = torch.zeros(max(num_optim_iter, 1), device=delta.device)
-    it_idx = torch.zeros((), dtype=torch.long, device=delta.device)
-
-    def iteration():
-        cam = state["cam"]
-        if optimize_camera:
-            if cam_raw.is_cuda:
-                from . import ops
-                cam = ops.camera_normalize(cam_raw)
-            else:
-                cam = torch.cat([cam_raw[:, :3], torch.nn.functional.normalize(cam_raw[:, 3:], dim=-1)], dim=1)
-        total, pred_v = refine_total(renderer, solver, delta, cam, faces, masks, edts_barrier, boundaries,
-                                     mask_loss_wt, boundaries_reg_wt, edt_reg_wt, bdt_reg_wt, of_loss_wt,
-                                     optical_flows, of_renderer, num_frames)
-        opt.zero_grad(set_to_none=True)
-        total.backward()
-        opt.step()
-        hist_buf.index_put_((it_idx,), total.detach())      # loss log stays on the device
-        it_idx.add_(1)
-        state["cam_out"], state["pred_v"] = cam.detach(), pred_v.detach()
-
-    n_eager = num_optim_iter if not graphable else min(3, num_optim_iter)
-    if graphable and num_optim_iter > n_eager:
-        side = torch.cuda.Stream(device=delta.device)
-        side.wait_stream(torch.cuda.current_stream(delta.device))
-        with torch.cuda.stream(side):
-            for _ in range(n_eager):
-                iteration()
-        torch.cuda.current_stream(delta.device).wait_stream(side)
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            iteration()                      # recorded, not executed
-        for _ in range(num_optim_iter - n_eager):
-            graph.replay()
-        ops.invalidate_setups()              # the replays rewrote the loop's tensors without version bumps
-    else:
-        for _ in range(num_optim_iter):
-            iteration()
-    history = hist_buf[:num_optim_iter].tolist()
-    pred_v = state["pred_v"]
-    return (pred_v.clone() if pred_v is not None else None), state.get("cam_out", state["cam"]).clone(), \
-        delta.detach().clone(), history
+    graphable = use_graph and delta_v_res.is_cuda
+    r = ClipRefiner(renderer, solver, delta_v_res, cam_pred, faces, masks, edts_barrier, boundaries,
+                    optimize_camera=optimize_camera, mask_loss_wt=mask_loss_wt, boundaries_reg_wt=boundaries_reg_wt,
+                    edt_reg_wt=edt_reg_wt, bdt_reg_wt=bdt_reg_wt, of_loss_wt=of_loss_wt, optical_flows=optical_flows,
+                    of_renderer=of_renderer, num_frames=num_frames, lr=lr, capturable=graphable, log_len=num_optim_iter)
+    done = 0
+    if graphable and num_optim_iter > 3:
+        done = r.capture(3)
+    for _ in range(num_optim_iter - done):
+        r.step()
+    history = r.history()
+    pred_v = r.pred_v
+    return (pred_v.clone() if pred_v is not None else None), r.cam_out.clone(), r.delta.detach().clone(), history

@@ -147,6 +147,7 @@ class SharedShapeExchange:
         self.group, self.average, self.deterministic = group, average, deterministic
         self._flat = None
         self._P = self._P_leaf = self._mean_leaf = None
+        self.bytes, self._n_sc, self._shapes = 0, 0, None
 
     def apply(self, delta):
         """delta [n_local,K_h,3] -> pred_v [n_local,V,3]; one factorisation per call (lbs / mean shape may have moved)."""
@@ -165,20 +166,35 @@ class SharedShapeExchange:
             self._flat = torch.zeros(n, dtype=torch.float32, device=device)
         return self._flat
 
-    def finish(self, extra_scalars=None):
+    # finish() = pack() -> reduce() -> unpack(); the three stages are public so that a step replayed from a hipGraph can
+    # capture pack() (the last launches of the local backward) and run the collective + the solve's backward after the
+    # replay (bench.py --gpus N), and so that several exchanges -- one per template of a mixed batch, BASELINE config 4
+    # -- can share ONE collective (finish_many).
+    def pack(self, gP=None, gmean=None, extra_scalars=None):
+        """Write [G | sum g | extra shared grads | scalars] into the persistent flat buffer (one torch.cat launch).
+        gP / gmean default to the .grad of the (P, mean) leaves of the last apply()."""
         s = self.solver
-        gP = self._P_leaf.grad if self._P_leaf.grad is not None else torch.zeros_like(self._P_leaf)
-        gm = self._mean_leaf.grad if self._mean_leaf.grad is not None else torch.zeros_like(self._mean_leaf)
+        if gP is None:
+            gP = self._P_leaf.grad if self._P_leaf.grad is not None else torch.zeros_like(self._P_leaf)
+        if gmean is None:
+            gmean = self._mean_leaf.grad if self._mean_leaf.grad is not None else torch.zeros_like(self._mean_leaf)
         if s.mean_v.requires_grad and s.mean_v.grad is not None:       # the direct paths (priors on the template)
-            gm = gm + s.mean_v.grad
-        parts = [gP.reshape(-1), gm.reshape(-1)]
+            gmean = gmean + s.mean_v.grad
+        parts = [gP.reshape(-1), gmean.reshape(-1)]
         parts += [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.extra]
-        n_sc = 0 if extra_scalars is None else extra_scalars.numel()
-        if n_sc:
+        self._n_sc = 0 if extra_scalars is None else extra_scalars.numel()
+        if self._n_sc:
             parts.append(extra_scalars.detach().reshape(-1).float())
         n = sum(p.numel() for p in parts)
         flat = self._buffer(n, gP.device)
         torch.cat(parts, out=flat)
+        self._shapes = (tuple(gP.shape), tuple(gmean.shape))
+        self.bytes = 4 * n
+        return flat
+
+    def reduce(self, flat=None):
+        """The ONE collective: all-reduce (sum; mean of the gradient part with average=True) of the packed buffer."""
+        flat = self._flat if flat is None else flat
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world > 1:
             staged = flat.is_cuda and dist.get_backend(self.group) == "gloo"   # CPU rehearsal of the multi-rank path
@@ -193,22 +209,81 @@ class SharedShapeExchange:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             if staged:
                 flat.copy_(buf)
-        n_grad = n - n_sc
         if self.average and world > 1:
-            flat[:n_grad].div_(world)
-        o = gP.numel()
-        G = flat[:o].view_as(gP)
+            flat[:flat.numel() - self._n_sc].div_(world)
+        return flat
+
+    def unpack(self, flat=None):
+        """Reduced buffer -> solver.lbs.grad (through the solve's backward, identical on every rank), solver.mean_v.grad,
+        the extra parameters' grads; returns the reduced scalars (or None)."""
+        s = self.solver
+        flat = self._flat if flat is None else flat
+        pshape, mshape = self._shapes
+        o = 1
+        for d in pshape:
+            o *= d
+        G = flat[:o].view(pshape)
         if s.lbs.requires_grad:
             direct, s.lbs.grad = s.lbs.grad, None                     # a direct term on lbs (a regulariser: replicated,
-            self._P.backward(G)                                       # identical on every rank) is kept, like mean_v's;
-            if direct is not None:                                    # d lbs through P = solve_backward(G), on every rank
-                s.lbs.grad = direct + s.lbs.grad if s.lbs.grad is not None else direct
-        mean_g = flat[o:o + gm.numel()].view_as(gm)
-        o += gm.numel()
+            # identical on every rank) is kept, like mean_v's; d lbs through P = solve_backward(G), on every rank.
+            # (autograd.grad with retain_graph: the factorisation's node may belong to a captured step that is replayed)
+            (g_lbs,) = torch.autograd.grad([self._P], [s.lbs], [G], retain_graph=True)
+            s.lbs.grad = g_lbs if direct is None else direct + g_lbs
+        nm = 1
+        for d in mshape:
+            nm *= d
         if s.mean_v.requires_grad:
-            s.mean_v.grad = mean_g.clone()
+            s.mean_v.grad = flat[o:o + nm].view(mshape).clone()
+        o += nm
         for p in self.extra:
             p.grad = flat[o:o + p.numel()].view_as(p).clone()
             o += p.numel()
-        self.bytes = 4 * n
-        return flat[n_grad:].clone() if n_sc else None
+        return flat[flat.numel() - self._n_sc:].clone() if self._n_sc else None
+
+    def finish(self, extra_scalars=None):
+        self.pack(extra_scalars=extra_scalars)
+        self.reduce()
+        return self.unpack()
+
+    @staticmethod
+    def reduce_many(exchanges):
+        """ONE collective for the packed buffers of several exchanges (one per template of a mixed batch): laid end to
+        end in a joint buffer, reduced together, handed back.  Nothing to do in a single-process run."""
+        head = exchanges[0]
+        world = dist.get_world_size(head.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        flats = [ex._flat for ex in exchanges]
+        n = sum(f.numel() for f in flats)
+        if getattr(head, "_joint", None) is None or head._joint.numel() != n or head._joint.device != flats[0].device:
+            head._joint = torch.zeros(n, dtype=torch.float32, device=flats[0].device)
+        joint = head._joint
+        torch.cat(flats, out=joint)
+        # (scalars sit inside the joint buffer, at the end of each exchange's part: reduce everything as sums here and
+        # average the gradient parts per exchange below)
+        avg, n_sc, head.average, head._n_sc = head.average, head._n_sc, False, 0
+        try:
+            head.reduce(joint)
+        finally:
+            head.average, head._n_sc = avg, n_sc
+        o = 0
+        for ex, f in zip(exchanges, flats):
+            part = joint[o:o + f.numel()]
+            if ex.average:
+                part[:f.numel() - ex._n_sc].div_(world)
+            f.copy_(part)
+            o += f.numel()
+        head.bytes = 4 * n
+
+    @staticmethod
+    def finish_many(exchanges, extra_scalars=None):
+        """pack() of every exchange (the scalars ride with the first), reduce_many(), unpack() of every exchange.
+        -> the reduced scalars."""
+        for i, ex in enumerate(exchanges):
+            ex.pack(extra_scalars=extra_scalars if i == 0 else None)
+        SharedShapeExchange.reduce_many(exchanges)
+        out = None
+        for ex in exchanges:
+            r = ex.unpack()
+            out = r if out is None else out
+        return out

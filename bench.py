@@ -5,11 +5,17 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch of frames (DESIGN.md section 6):
-deformation apply -> soft-silhouette render (K=20) -> fused L1/IoU/EDT losses -> boundary
-loss -> atlas-texture render + MSE -> backward to handle offsets, cameras, shared mean shape
-and atlas.  Frames are sharded over ranks (weak scaling: 64 frames per GPU); the only
-exchange is one RCCL all-reduce of the shared-shape gradient.
+One step = one pass of the hot path over one batch of frames (DESIGN.md section 5):
+deformation apply -> soft-silhouette render (K=20) -> L1/IoU/EDT losses -> boundary loss ->
+atlas-texture render + MSE -> backward to handle offsets, cameras, shared shape and atlas.
+Frames are sharded over ranks (weak scaling: 64 frames per GPU); the only exchange is ONE RCCL
+all-reduce per step.  With --gpus N > 1 the shared parameters are the handle weights (lbs) AND the mean
+shape (multiframe/nnutils/mesh_net.py:543-544): every step re-factorises the deformation system and the ranks
+exchange the pre-solve sums [G = sum g delta^T | sum g | loss] (sharding.SharedShapeExchange); --shared mean
+keeps the handle weights fixed and exchanges the mean-shape gradient alone (what --gpus 1 times).
+
+--config 3 / 4 / 5: the other BASELINE.json workloads (32-frame horse refinement iteration; mixed horse / cow / bird
+shard of 32 frames per GPU with one exchange for the three templates; 5120-face 512^2 half-storage shard).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
 kernel, algorithmic bytes vs 8 TB/s HBM, durations from hipEvents on the launch stream) and
@@ -31,6 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_TAGS = ("r03", "r02", "r01")
 
 
 def parse():
@@ -38,15 +45,17 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--config", type=int, default=2, choices=(2, 5),
-                   help="BASELINE.json configs[1] (default: bird, 64 frames @256^2, fp32, drop-in API) or configs[4], one "
-                        "GPU's share of it (5120-face subdivided horse, 16 frames @512^2, half storage with fp32 loss sums, "
-                        "fused render+loss operators)")
-    p.add_argument("--frames", type=int, default=None, help="frames per GPU (64; config 5: 16)")
+    p.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                   help="BASELINE.json configs[1] (default: bird, 64 frames @256^2, fp32, drop-in API); configs[2] (3: one Adam "
+                        "iteration of the test-time refinement of a 32-frame horse clip @256^2, handle offsets + cameras); "
+                        "configs[3] (4: one GPU's share of the mixed batch -- 32 frames @256^2, horse / cow / bird interleaved, "
+                        "lbs + mean shape of the three templates learned, one exchange); configs[4] (5: one GPU's share -- "
+                        "5120-face subdivided horse, 16 frames @512^2, half storage with fp32 loss sums, fused render+loss)")
+    p.add_argument("--frames", type=int, default=None, help="frames per GPU (64; config 3 / 4: 32; config 5: 16)")
     p.add_argument("--img", type=int, default=None, help="image size (256; config 5: 512)")
     p.add_argument("--handles", type=int, default=16)
     p.add_argument("--tex", type=int, default=1, help="include the atlas-texture render + loss")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-oracle time budget")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle time budget per leg")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-lean", action="store_true", help="skip the all-slots-stored comparison run")
     p.add_argument("--headline-only", action="store_true",
@@ -54,10 +63,11 @@ def parse():
                         "trace then belongs to the same workload)")
     p.add_argument("--eager", action="store_true",
                    help="launch every kernel of the step from Python instead of replaying one captured hipGraph")
-    p.add_argument("--learn-lbs", action="store_true",
-                   help="handle weights (lbs) and mean shape are learned shared parameters: every step re-factorises the "
-                        "deformation system and the ranks exchange the pre-solve sums [G = sum g delta^T | sum g | loss] "
-                        "(~50 KB, sharding.SharedShapeExchange) instead of the mean-shape gradient alone; eager launches")
+    p.add_argument("--shared", choices=("auto", "shape", "mean"), default="auto",
+                   help="shared parameters of the sharded step: 'shape' = handle weights (lbs) + mean shape, per-step "
+                        "factorisation, pre-solve exchange [G | sum g | loss] (default with --gpus N > 1); 'mean' = mean shape "
+                        "only, fixed handle weights (default with --gpus 1: BASELINE config 2 as quoted)")
+    p.add_argument("--learn-lbs", action="store_true", help="same as --shared shape")
     p.add_argument("--tex-stream", type=int, default=0,
                    help="texture branch forked onto its own HIP stream behind the silhouette forward (graph edges in a capture); "
                         "measured: no gain, 0.693 vs 0.689 ms/step -- every kernel of either branch fills the chip")
@@ -78,32 +88,243 @@ def edt_and_boundaries(gt_mask):
     return edt.contiguous(), bds.contiguous()
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # ACFM_DIST_BACKEND=gloo + ACFM_ALL_RANKS_ON_GPU0=1: rehearsal of the multi-rank control flow
-    # on a one-GPU box (collectives through the host); the real runs use nccl (= RCCL over xGMI)
-    backend = os.environ.get("ACFM_DIST_BACKEND", "nccl")
-    if os.environ.get("ACFM_ALL_RANKS_ON_GPU0") == "1":
-        local = 0
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+class Ctx:
+    """Process / device context shared by the workloads: fences, max-over-ranks timing, graph capture."""
 
+    def __init__(self, a):
+        self.a = a
+        self.rank = int(os.environ.get("RANK", 0))
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        # ACFM_DIST_BACKEND=gloo + ACFM_ALL_RANKS_ON_GPU0=1: rehearsal of the multi-rank control flow
+        # on a one-GPU box (collectives through the host); the real runs use nccl (= RCCL over xGMI)
+        self.backend = os.environ.get("ACFM_DIST_BACKEND", "nccl")
+        if os.environ.get("ACFM_ALL_RANKS_ON_GPU0") == "1":
+            local = 0
+        self.dev = torch.device("cuda", local)
+        torch.cuda.set_device(self.dev)
+        import torch.distributed as dist
+        self.dist = dist
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        self.graph_note = []
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def tmax(self, dt):
+        if self.world > 1:
+            t = torch.tensor([dt], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def capture(self, fn, what="step"):
+        """fn() three times on a side stream, then once recorded into a hipGraph: -> (graph, fn's recorded outputs), or
+        (None, None) with a note when the capture fails (the measurement then launches eagerly)."""
+        try:
+            cur = torch.cuda.current_stream(self.dev)
+            s2 = torch.cuda.Stream(device=self.dev)
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s2):
+                for _ in range(3):
+                    fn()
+            cur.wait_stream(s2)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                outs = fn()
+            return g, outs
+        except Exception as exc:   # never lose the measurement to a capture problem: fall back, and say so
+            torch.cuda.synchronize()
+            self.graph_note.append("%s: capture failed (%s: %s), eager launch instead" % (what, type(exc).__name__, str(exc)[:200]))
+            return None, None
+
+    def time_steps(self, fn, warmup, steps):
+        """W untimed + exactly K timed calls of fn(), barrier + synchronize on both sides, max over ranks."""
+        for _ in range(warmup):
+            fn()
+        # the previous measurement's hipGraph (and its private memory pool) sits in a reference cycle: collect it
+        # here, not in the middle of this one's timed steps (its hipFree stalls the host for tens of ms)
+        gc.collect()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.fence()
+        return self.tmax(time.perf_counter() - t0)
+
+    def leg(self, dt, frames, steps, note=None, **more):
+        d = {"value": round(self.world * frames * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 4)}
+        if note:
+            d["note"] = note
+        d.update(more)
+        return d
+
+
+def kernel_profile(ctx, fn, steps):
+    """Per-kernel durations (hipEvents on the launch stream) over `steps` eager calls of fn() on every rank."""
     from acfm_video_3d_reconstruction_amd import _lib
+    lib = _lib.lib()
+    kern = {}
+    if ctx.rank == 0:
+        lib.acfm_prof_enable(1)
+    for _ in range(steps):  # every rank runs the same steps (the exchange is collective)
+        fn()
+    ctx.fence()
+    if ctx.rank == 0:
+        ms = (ctypes.c_float * 24)()
+        cnt = (ctypes.c_int * 24)()
+        _lib.check(lib.acfm_prof_collect(ms, cnt, 24), "acfm_prof_collect")
+        lib.acfm_prof_enable(0)
+        for i in range(24):
+            if cnt[i]:
+                kern[lib.acfm_prof_name(i).decode()] = dict(avg_us=1e3 * ms[i] / cnt[i], launches=cnt[i],
+                                                            us_per_step=1e3 * ms[i] / steps)
+    return kern
+
+
+def algorithmic_bytes(N, H, V, F, R, half=False):
+    """ALGORITHMIC bytes per launch."""
+    if half:   # half storage, int32 nearest-face plane, fused losses (SURVEY 8d with the halved terms)
+        return {
+            # write mask 2H^2 + id 4H^2, read gt 2H^2 + edt 2H^2, verts 12V, cam 28 (+ faces 12F once)
+            "k_raster_fwd<K,soft>": N * (10 * H * H + 12 * V + 28) + 12 * F,
+            # read mask 2H^2 + gt 2H^2 + edt 2H^2 (no mask gradient: formed in the kernel), write grads 12V + 28
+            "k_sil_bwd": N * (6 * H * H + 12 * V + 28),
+            # read atlas 6FR^2 + reference image 6H^2 + mask 2H^2; write image 6H^2 + sil 2H^2 + id 4H^2
+            "k_raster_fwd<1,tex>": N * (20 * H * H + 6 * F * R * R + 12 * V + 28),
+            # read image 6H^2 + reference 6H^2 + mask 2H^2; write the float atlas gradient 12FR^2
+            "k_tex_bwd": N * (14 * H * H + 12 * F * R * R),
+        }
+    return {
+        # read verts 12V + cam 28 (+ faces 12F shared, once per batch); write mask 4H^2 + nearest face id 8H^2
+        "k_raster_fwd<K,soft>": N * (12 * H * H + 12 * V + 28) + 12 * F,
+        # read grad 4H^2 + mask 4H^2 + K-th key 8H^2; write grad_verts 12V + grad_cam 28
+        "k_sil_bwd": N * (16 * H * H + 12 * V + 28),
+        # read atlas 12FR^2 ; write image 12H^2 + sil 4H^2 + face id 8H^2
+        "k_raster_fwd<1,tex>": N * (24 * H * H + 12 * F * R * R + 12 * V + 28),
+        "k_tex_bwd": N * (12 * H * H + 4 * H * H + 12 * F * R * R),
+        "k_mask_losses": N * 12 * H * H, "k_mask_losses_bwd": N * 16 * H * H,
+    }
+
+
+def roofline_of(kern, alg, workload_key):
+    """`roofline` object of the dominant kernel.  workload_key = (frames, img, K, mesh, storage): the committed PMC pass of
+    exactly this workload (profiles/rNN_pmc_traffic.json; counters cannot be read from inside this process) is quoted for
+    `traffic` and the VALU figures, else they stay null."""
+    # the dominant kernel among those that stream images (the per-step factorisation of the deformation system, where a
+    # workload has one, is a latency-bound fp64 chain with no HBM term: DESIGN.md section 4)
+    dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["us_per_step"])
+    ab = alg.get(dom, 0)
+    ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
+    traffic, traffic_src, pmk = None, None, None
+    for tag in PROFILE_TAGS:
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)))
+            for w, ks in ([(pm["workload"], pm["kernels"])] + [(x["workload"], x["kernels"]) for x in pm.get("more", [])]):
+                same = (w["frames"], w["img"], w["K"], w.get("mesh", "bird"), w.get("storage", "f32")) == workload_key
+                if same and dom in ks:
+                    pmk = ks[dom]
+                    traffic = pmk["fetch_bytes"] + pmk["write_bytes"]
+                    traffic_src = "profiles/%s_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch, own --pmc passes)" % tag
+                    break
+            if pmk:
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
+                algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
+    if pmk and pmk.get("valu_insts"):
+        # What limits the kernel is VALU issue, not HBM.  Issue rates measured on this part with independent
+        # instruction streams at 4 waves per SIMD (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt):
+        # fp32 add / mul / fma, integer add, and: 1.21 ns per wave-instruction and SIMD (844 G/s on 1024 SIMDs);
+        # selects, compares, min / max / med3, shifts, 64-bit moves, DPP, packed fp32: 1.75-1.95 ns (525-585 G/s);
+        # rcp / exp / sqrt: 3.5 ns (293 G/s).  The raster kernels' stream is mostly the second class (the sorted
+        # insertion is one 64-bit compare + six selects per slot), so its ceiling lies between the two figures.
+        rate = pmk["valu_insts"] / (kern[dom]["avg_us"] * 1e-6)
+        v = dict(insts_per_launch=pmk["valu_insts"], achieved_ginst_s=round(rate / 1e9, 1),
+                 full_rate_ginst_s=844.4, half_rate_class_ginst_s=572.7,
+                 frac_of_full_rate=round(rate / 844.4e9, 4), frac_of_half_rate_class=round(rate / 572.7e9, 4),
+                 source=traffic_src.split(" ")[0] + " (SQ_INSTS_VALU), profiles/r02_valu_rates.txt (rates)")
+        if pmk.get("active_inst_valu") and pmk.get("grbm_gui_active"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            v["valu_busy"] = round(pmk["active_inst_valu"] * 4 / (1024 * pmk["grbm_gui_active"] / 8), 4)
+            v["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): an estimate, a few % above 1 when saturated"
+        if pmk.get("thread_cycles_valu") and pmk.get("active_inst_valu"):
+            v["lanes_active"] = round(pmk["thread_cycles_valu"] / (64 * pmk["active_inst_valu"]), 4)
+        roof["valu"] = v
+        roof["limiter"] = {
+            "k_sil_bwd": "VALU issue (per pixel x face pair: membership test key <= kth, exact edge distance again, its "
+                         "backward to three vertices, 4 DPP row shifts per gradient component before the LDS accumulators)",
+        }.get(dom, "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)")
+    if traffic:   # what the kernel actually moves: context, not `achieved`
+        moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
+    return roof
+
+
+def host_cores():
+    # host-core share of a one-GPU box (the pool's guidance: 16 workers per GPU)
+    return min(16, len(os.sched_getaffinity(0)))
+
+
+def cpu_legs(a, run_frames, N, what_full, what_render=None, run_render=None):
+    """CPU baseline (rank 0, N = 1): the oracle on this box's host cores, bounded samples.  run_frames(k) runs the
+    like-for-like step on k frames and returns nothing; timed with `cores` threads and with ONE thread.
+    -> (cpu_baseline object, extra dict)."""
+    from oracle import oracle as O
+    cores = host_cores()
+
+    def rate(fn, threads, budget):
+        n_thr = O.set_threads(threads)
+        torch.set_num_threads(max(1, threads))
+        t = time.perf_counter()
+        fn(1)
+        t1 = time.perf_counter() - t
+        k = int(max(1, min(N, budget / max(t1, 1e-3))))
+        if k > 1:
+            t = time.perf_counter()
+            fn(k)
+            tk = time.perf_counter() - t
+        else:
+            tk = t1
+        return k / tk, k, n_thr
+    try:
+        r_full, k_full, n_thr = rate(run_frames, cores, a.cpu_seconds)
+        r_one, k_one, _ = rate(run_frames, 1, a.cpu_seconds / 3)
+        cpu = dict(value=round(r_full, 3), unit="frames/s", cores=n_thr, kind="port",
+                   sample="%s, %d frame(s), oracle (C, OpenMP over rows) + torch-CPU, %d threads" % (what_full, k_full, n_thr),
+                   single_thread=dict(value=round(r_one, 3), unit="frames/s", cores=1,
+                                      sample="the same step, %d frame(s), 1 thread" % k_one))
+        if run_render is not None:
+            r_ren, k_ren, _ = rate(run_render, cores, a.cpu_seconds / 2)
+            cpu["render_only"] = dict(value=round(r_ren, 3), unit="frames/s", cores=n_thr,
+                                      sample="%s, %d frame(s)" % (what_render, k_ren))
+    finally:
+        O.set_threads(cores)
+        torch.set_num_threads(max(1, cores))
+    return cpu
+
+
+# ====================================================================================================== configs 2 and 5
+def run_config2_or_5(ctx):
+    a, rank, world, dev = ctx.a, ctx.rank, ctx.world, ctx.dev
+    import torch.nn.functional as Fnn
+    from acfm_video_3d_reconstruction_amd import _lib, ops
     from acfm_video_3d_reconstruction_amd.deform import DeformSolver
     from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
     from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
-    from acfm_video_3d_reconstruction_amd.sharding import SharedGradReducer
+    from acfm_video_3d_reconstruction_amd.sharding import SharedGradReducer, SharedShapeExchange
     from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
 
     cfg5 = a.config == 5
@@ -111,6 +332,11 @@ def main():
         a.no_lean = a.no_cpu = True
     a.frames = a.frames or (16 if cfg5 else 64)
     a.img = a.img or (512 if cfg5 else 256)
+    shared = a.shared if a.shared != "auto" else ("shape" if (world > 1 or a.learn_lbs) else "mean")
+    if a.learn_lbs:
+        shared = "shape"
+    if cfg5:
+        shared = "mean"
     N, H, Kh = a.frames, a.img, a.handles
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
     v_np, f_np = m["bird_v"], m["bird_f"]
@@ -146,28 +372,20 @@ def main():
     mean_p = mean_v.clone().requires_grad_(True)
     reducer = SharedGradReducer([mean_p])  # one flat fp32 all-reduce (RCCL) per step
     _flat, flat_views, flat_extra = reducer.packed(n_extra=1)
-
     params = [delta, cams, mean_p, atlas]
-
     side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
-
     if cfg5:   # references and atlas held in half by the caller (what ACFM_STORE_F16 reads); the atlas gradient stays float
         gt_h, edt_h, imgs_h = gt_mask.half(), edt.half(), imgs_gt.half()
-
     seed = torch.ones((), device=dev)   # d total / d total, made once (autograd.grad would fill a fresh one every step)
+    W_SIL = [1.0, 0.0, 0.0, 0.1]        # weights of the [N,4] silhouette-loss vector (l1, iou sums, edt); then bds 0.1, texture 0.5
 
-    def compute(ren, fused=False):
-        pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
+    def losses_of(ren, pred_v, fused):
+        """render + losses of one batch of deformed vertices -> total (the step's graph from pred_v on)"""
         if cfg5:
             sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_h, edt_h, raw=True)
             bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
             tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_h, gt_h)[0]
-            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
-            g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, grad_outputs=seed)
-            if world > 1:
-                flat_views[0].copy_(g_mean)
-                flat_extra.copy_(total.detach().reshape(1))
-            return total.detach(), g_delta, g_cams, g_mean, g_atlas
+            return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
         if fused:   # opt-in operator: the loss terms leave the raster kernel with the mask (acfm_sil_loss_*)
             sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_mask, edt, raw=True)
         else:
@@ -190,16 +408,20 @@ def main():
         # (combine_losses) instead of ~13 elementwise launches on 64-element vectors
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
-        elif a.tex:
+            return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
+        if a.tex:
             if fused:
                 tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_gt, gt_mask)[0]
             else:
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
                 tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)                   # main.py:655-662
-            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
-        else:
-            total = L.combine_losses([sil4, bdt], [1.0, 0.0, 0.0, 0.1, 0.1])
+            return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
+        return L.combine_losses([sil4, bdt], W_SIL + [0.1])
+
+    # ---------------------------------------------------------------- shared = mean: fixed handle weights (config 2 as quoted)
+    def compute(ren=renderer, fused=False):
+        pred_v = solver(delta, mean_override=mean_p)                      # a8 (closed form)
+        total = losses_of(ren, pred_v, fused)
         # gradients of the per-frame parameters (handle offsets, cameras), the shared mean shape
         # and the atlas; autograd.grad hands the buffers over without AccumulateGrad's copies
         g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, params, grad_outputs=seed, allow_unused=not a.tex)
@@ -210,170 +432,161 @@ def main():
             flat_extra.copy_(total.detach().reshape(1))
         return total.detach(), g_delta, g_cams, g_mean, g_atlas
 
-    def exchange(total, g_mean):
+    def exchange(outs):
         if world > 1:  # the one exchange: shared mean-shape gradient + loss scalar
             reducer.reduce_packed()
             mean_p.grad = flat_views[0]
         else:
-            mean_p.grad = g_mean
+            mean_p.grad = outs[3]
 
-    def step(ren=renderer, fused=False):
-        total, g_delta, g_cams, g_mean, g_atlas = compute(ren, fused)
-        exchange(total, g_mean)
-        return total, g_delta, g_cams, g_atlas
+    # ---------------------------------------------------------------- shared = shape: lbs + mean shape learned (north star)
+    lbs_q = torch.nn.Parameter(lbs_logits.clone())
+    mean_l = torch.nn.Parameter(mean_v.clone())
+    solver_l = DeformSolver(mean_l, faces[0], lbs_q)
+    ex = SharedShapeExchange(solver_l)
 
-    def graphed(ren, fused=False):
-        """The same step with its ~60 launches (forward, backward, every gradient buffer) captured
-        once into a hipGraph and replayed: shapes are static, every entry point of libacfm_hip.so is
-        stream-ordered, so the step runs at the GPU's pace whatever the host's launch rate is (with
-        8 ranks on one host the Python launch loop is the first thing to fall behind).  The all-reduce
-        of the shared gradient stays an ordinary RCCL call on the replayed buffers."""
-        cur = torch.cuda.current_stream(dev)
-        s2 = torch.cuda.Stream(device=dev)
-        s2.wait_stream(cur)
-        with torch.cuda.stream(s2):
-            for _ in range(3):
-                compute(ren, fused)
-        cur.wait_stream(s2)
-        g = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            outs = compute(ren, fused)
+    def compute_shape(ren=renderer, fused=False):
+        # one cot Laplacian + one fp64 factorisation per step (lbs / mean shape moved), then the deformation apply on
+        # (P, mean) LEAVES: the local backward stops there with exactly the pre-solve sums dL/dP = sum g delta^T, dL/dmean = sum g
+        pred_v = ex.apply(delta)
+        total = losses_of(ren, pred_v, fused)
+        g_delta, g_cams, g_atlas, gP, gmean = torch.autograd.grad(total, [delta, cams, atlas, ex._P_leaf, ex._mean_leaf],
+                                                                  grad_outputs=seed, allow_unused=not a.tex)
+        ex.pack(gP, gmean, extra_scalars=total.detach().reshape(1))     # [G | sum g | loss] -> the exchange buffer (one cat)
+        return total.detach(), g_delta, g_cams, None, g_atlas
 
-        def replay(_ren=None):
-            g.replay()
-            exchange(outs[0], outs[3])
-            return outs[0], outs[1], outs[2], outs[4]
-        return replay
+    def exchange_shape(outs):
+        ex.reduce()      # ONE all-reduce (RCCL) of ~49 KB
+        ex.unpack()      # d lbs = solve_backward(G) on every rank (acfm_deform_solve_backward), mean-shape gradient
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    graph_note = []
-
-    def timed(ren, warmup, steps, use_graph=None, fused=False):
-        use_graph = (not a.eager) if use_graph is None else use_graph
-        fn = (lambda r: step(r, True)) if fused else step
+    def make_step(shape_mode, ren=renderer, fused=False, use_graph=True):
+        comp = (lambda: compute_shape(ren, fused)) if shape_mode else (lambda: compute(ren, fused))
+        exch = exchange_shape if shape_mode else exchange
         if use_graph:
-            try:
-                fn = graphed(ren, fused)
-            except Exception as exc:   # never lose the measurement to a capture problem: fall back, and say so
-                torch.cuda.synchronize()
-                graph_note.append("capture failed (%s: %s), eager launch instead" % (type(exc).__name__, str(exc)[:200]))
-        for _ in range(warmup):
-            fn(ren)
-        # the previous measurement's hipGraph (and its private memory pool) sits in a reference cycle: collect it
-        # here, not in the middle of this one's timed steps (its hipFree stalls the host for tens of ms)
-        gc.collect()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn(ren)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            # The step's ~60 launches (forward, backward, every gradient buffer, the pack of the exchange buffer) captured
+            # once into a hipGraph and replayed: shapes are static, every entry point of libacfm_hip.so is stream-ordered,
+            # so the step runs at the GPU's pace whatever the host's launch rate is (with 8 ranks on one host the Python
+            # launch loop is the first thing to fall behind).  The exchange stays an ordinary RCCL call on the replayed
+            # buffers (+ the solve's backward with --shared shape).
+            g, outs = ctx.capture(comp, "shape step" if shape_mode else "step")
+            if g is not None:
+                def replay():
+                    g.replay()
+                    exch(outs)
+                    return outs
+                return replay, True
+        def eager():
+            outs = comp()
+            exch(outs)
+            return outs
+        return eager, False
 
-    # ---- --learn-lbs: the exchange the north star names (shared mean-shape AND handle-weight gradients)
-    lbs_info = None
-    if a.learn_lbs:
-        from acfm_video_3d_reconstruction_amd.sharding import SharedShapeExchange
-        lbs_q = torch.nn.Parameter(lbs_logits.clone())
-        mean_l = torch.nn.Parameter(mean_v.clone())
-        solver_l = DeformSolver(mean_l, faces[0], lbs_q)
-        ex = SharedShapeExchange(solver_l)
-
-        def lbs_step(ren=renderer):
-            pred_v = ex.apply(delta)                                       # one factorisation per step + deform apply
-            mask, p2f = ren(pred_v, faces, cams)
-            sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)
-            bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
-            tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)
-            tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
-            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
-            for p_ in (delta, cams, atlas):
-                p_.grad = None
-            total.backward()                                               # local: stops at the (P, mean) leaves
-            ex.finish(extra_scalars=total.detach().reshape(1))             # ONE all-reduce + the solve's backward
-            return total
-        for _ in range(a.warmup):
-            lbs_step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            lbs_step()
-        fence()
-        dt_l = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt_l], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_l = float(t.item())
-        lbs_info = dict(value=round(world * N * a.steps / dt_l, 2), unit="frames/s", ms_per_step=round(1e3 * dt_l / a.steps, 4),
-                        exchange_bytes=int(ex.bytes),
-                        note="lbs and mean shape learned: per-step factorisation + pre-solve exchange [G | sum g | loss], eager launches")
-
-    dt = timed(renderer, a.warmup, a.steps)          # the drop-in API: pix_to_face [N,H,W,20] int64
+    use_graph = not a.eager
+    headline_shape = shared == "shape"
+    step_fn, graphed = make_step(headline_shape, use_graph=use_graph)
+    dt = ctx.time_steps(step_fn, a.warmup, a.steps)          # the drop-in API: pix_to_face [N,H,W,20] int64
     ms_step = 1e3 * dt / a.steps
     value = world * N * a.steps / dt
-    use_graph = not a.eager
-    # the other launch mode of the same step, reported beside the headline (never instead of it)
-    extras = not cfg5 and not a.headline_only
-    dt_other = timed(renderer, max(2, a.warmup // 2), a.steps, use_graph=not use_graph) if side is None and extras else None
-    # same step with every slot of pix_to_face [N,H,W,20] stored at render time (160 bytes per pixel nobody in the
-    # step reads) instead of the default's nearest-face plane + the other planes on first use; beside the headline
-    dt_lean = None
-    if not a.no_lean and not cfg5:
+    ops.invalidate_setups()
+    half_w = max(2, a.warmup // 2)
+    extras = not cfg5 and not a.headline_only and side is None
+    legs = {}
+    if extras:
+        # the other launch mode of the same step, reported beside the headline (never instead of it)
+        fn, _ = make_step(headline_shape, use_graph=not graphed)
+        legs["hipgraph_replay" if not graphed else "eager_launch"] = ctx.leg(ctx.time_steps(fn, half_w, a.steps), N, a.steps)
+        # the other choice of shared parameters, same run: with --gpus 1 this is the step --gpus N > 1 times per GPU
+        # (the base of a like-for-like scaling ratio); with --gpus N the mean-only exchange of rounds 1-2
+        fn, g_ok = make_step(not headline_shape, use_graph=use_graph)
+        legs["shared_shape_step" if not headline_shape else "mean_only_exchange"] = ctx.leg(
+            ctx.time_steps(fn, half_w, a.steps), N, a.steps,
+            note=("lbs + mean shape learned: cot Laplacian + fp64 factorisation + lbs gradient every step, exchange "
+                  "[G = sum g delta^T | sum g | loss] (%d bytes); what --gpus N > 1 times per GPU" % ex.bytes) if not headline_shape
+            else "fixed handle weights, the mean-shape gradient alone is exchanged (7.7 KB): the --gpus 1 headline step per GPU",
+            launch="one hipGraph replay per step" if g_ok else "eager")
+    if not a.no_lean and not cfg5 and side is None:
+        # same step with every slot of pix_to_face [N,H,W,20] stored at render time (160 bytes per pixel nobody in the
+        # step reads) instead of the default's nearest-face plane + the other planes on first use; beside the headline
         lean = NeuralRenderer(H, pix_to_face_slots=20)
-        dt_lean = timed(lean, max(2, a.warmup // 2), a.steps)
-
-    # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
-    # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
-    dt_fused = timed(renderer, max(2, a.warmup // 2), a.steps, fused=True) if side is None and extras else None
-    # same step with the bit-reproducible silhouette backward (fixed-point accumulation, AcfmRasterTuning flag 1)
-    dt_det = None
-    if side is None and extras:
+        fn, _ = make_step(headline_shape, ren=lean, use_graph=use_graph)
+        legs["all_slots_stored"] = ctx.leg(
+            ctx.time_steps(fn, half_w, a.steps), N, a.steps,
+            note="NeuralRenderer(pix_to_face_slots=20): all 20 planes of pix_to_face written by the render "
+                 "(the default returns the same [N,H,W,20] int64 tensor lazily: nearest-face plane written, "
+                 "the other planes rendered when first touched -- never, in this step)")
+    if extras:
+        # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
+        # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
+        fn, _ = make_step(headline_shape, fused=True, use_graph=use_graph)
+        legs["fused_render_loss"] = ctx.leg(
+            ctx.time_steps(fn, half_w, a.steps), N, a.steps,
+            note="same step, silhouette losses and the masked texture MSE fused into the raster kernels "
+                 "(NeuralRenderer.forward_silhouette_losses / forward_texture_mse: acfm_sil_loss_*, acfm_tex_mse_*)")
+        # same step with the bit-reproducible silhouette backward (fixed-point accumulation, AcfmRasterTuning flag 1)
         with _lib.raster_tuning(deterministic=True):
-            dt_det = timed(renderer, max(2, a.warmup // 2), a.steps)
+            fn, _ = make_step(headline_shape, use_graph=use_graph)
+            legs["deterministic_backward"] = ctx.leg(
+                ctx.time_steps(fn, half_w, a.steps), N, a.steps,
+                note="same step with _lib.raster_tuning(deterministic=True): the silhouette backward accumulates in "
+                     "2^-36 fixed point (int64 atomics), gradients bit-identical from run to run")
+
+    # ---- the reference's LITERAL call sequence (multiframe/main.py:616-720): only names main.py uses -- the renderers and
+    # Boundaries_Loss wrapped in nn.DataParallel (:183-193, :326), mirror_sample's flip of mask_pred (:98), l1_loss and
+    # edt_loss as separate reduce=False operators (:644, :716), the texture MSE written in torch ops (:655-662), the
+    # default (lazy) pix_to_face through DataParallel's scatter.  Beside the headline, never instead of it.
+    if extras and a.tex:
+        dp_renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()
+        dp_tex_renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()
+        dp_boundaries = torch.nn.DataParallel(L.Boundaries_Loss())
+
+        def reference_sequence():
+            pred_v = solver(delta, mean_override=mean_p)
+            mask_pred, pix_to_face = dp_renderer(pred_v, faces, cams)
+            texture_pred, _, _ = dp_tex_renderer(pred_v.detach(), faces, cams, textures=atlas)
+            mask_pred_flip = torch.flip(mask_pred, dims=(2,))
+            mask_loss = L.l1_loss(mask_pred, gt_mask, reduce=False)
+            tex_l1 = Fnn.mse_loss(texture_pred * gt_mask.unsqueeze(1), imgs_gt * gt_mask.unsqueeze(1), reduction='none')
+            tex_l1 = tex_l1.mean((1, 2, 3))
+            pred_proj = dp_renderer.module.project_points(pred_v, cams)
+            edt_loss = L.edt_loss(mask_pred, edt, reduce=False)
+            bdt_loss = dp_boundaries(pred_proj, bds, faces, pix_to_face, reduce=False)
+            total = (1.0 * mask_loss + 0.1 * edt_loss + 0.1 * bdt_loss).mean() + 0.5 * tex_l1.mean()
+            grads = torch.autograd.grad(total, params, grad_outputs=seed)
+            return total.detach(), grads, mask_pred_flip
+        rg, _ = (ctx.capture(reference_sequence, "reference_call_sequence") if use_graph else (None, None))
+        dt_ref = ctx.time_steps(rg.replay if rg is not None else reference_sequence, half_w, a.steps)
+        ops.invalidate_setups()
+        legs["reference_call_sequence"] = ctx.leg(
+            dt_ref, N, a.steps,
+            note="the step written with the reference's own calls only (main.py:616-720): DataParallel(NeuralRenderer) x 2, "
+                 "DataParallel(Boundaries_Loss), torch.flip of mask_pred, l1_loss / edt_loss(reduce=False) as separate "
+                 "operators, the texture MSE as F.mse_loss on texture_pred * masks, torch arithmetic for the total",
+            launch="one hipGraph replay per step" if rg is not None else "eager",
+            headline_over_this=round((dt_ref / a.steps) / (dt / a.steps), 3))
 
     # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
     # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
-    dt_render = None
     if extras:
         rv = solver(delta0).detach().requires_grad_(True)
         rc = cams0.clone().requires_grad_(True)
         rw = torch.randn(N, H, H, device=dev) / (H * H)
 
         def render_only():
-            m, _ = renderer(rv, faces, rc)
-            return torch.autograd.grad((m * rw).sum(), [rv, rc])
-        for _ in range(max(2, a.warmup // 2)):
-            render_only()
+            mk, _ = renderer(rv, faces, rc)
+            return torch.autograd.grad((mk * rw).sum(), [rv, rc])
         dt_render = None
-        for _round in range(2):   # eager launches with a fresh 671 MB output per call: one allocator hiccup would show
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                render_only()
-            fence()
-            dt = time.perf_counter() - t0
-            dt_render = dt if dt_render is None else min(dt_render, dt)
-        if world > 1:
-            t = torch.tensor([dt_render], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_render = float(t.item())
+        for _round in range(2):   # eager launches: one allocator hiccup would show
+            d_ = ctx.time_steps(render_only, half_w if _round == 0 else 0, a.steps)
+            dt_render = d_ if dt_render is None else min(dt_render, d_)
+        legs["render_only"] = ctx.leg(dt_render, N, a.steps,
+                                      note="soft-silhouette render K=20 (pix_to_face [N,H,W,20] as the default lazy tensor) + backward to "
+                                           "vertices and cameras only; eager launches")
 
     # ---- SURVEY section 8d's step, every row of it: the headline step + the per-optimiser-step factorisation
     # of the deformation system with learned handle weights (a8: cot Laplacian, fp64 Cholesky, lbs gradient)
     # + the mesh priors on the deformed shape (a14 locally_rigid_fn, a15 mesh_laplacian_smoothing 'cot');
     # reported beside the headline value, never instead of it
-    dt_full = None
-    if a.tex and side is None and extras:
+    if a.tex and extras:
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.loss import mesh_laplacian_smoothing
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
         lbs_p = torch.nn.Parameter(lbs_logits.clone())
@@ -400,212 +613,318 @@ def main():
             tex, _, _ = renderer(pred_v.detach(), faces, cams, textures=atlas)
             tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
             cur_s.wait_stream(prior_s)
-            total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5]) + prior
+            total = L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5]) + prior
             return torch.autograd.grad(total, params2, grad_outputs=seed)
-        full_fn, full_mode = full_step, "eager launches"
-        if not a.eager:
-            try:                                   # the same step as one hipGraph (forward + backward, static shapes)
-                cur = torch.cuda.current_stream(dev)
-                s3 = torch.cuda.Stream(device=dev)
-                s3.wait_stream(cur)
-                with torch.cuda.stream(s3):
-                    for _ in range(3):
-                        full_step()
-                cur.wait_stream(s3)
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                    full_outs = full_step()
-                full_fn, full_mode = g2.replay, "one hipGraph replay per step"
-            except Exception as exc:
-                torch.cuda.synchronize()
-                graph_note.append("survey_8d_step: capture failed (%s), eager launch instead" % type(exc).__name__)
-        for _ in range(max(2, a.warmup // 2)):
-            full_fn()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            full_fn()
-        fence()
-        dt_full = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt_full], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_full = float(t.item())
+        g2, _ = (ctx.capture(full_step, "survey_8d_step") if use_graph else (None, None))
+        legs["survey_8d_step"] = ctx.leg(
+            ctx.time_steps(g2.replay if g2 is not None else full_step, half_w, a.steps), N, a.steps,
+            note="headline step + per-step factorisation of the deformation system with learned handle weights "
+                 "(cot Laplacian, fp64 Cholesky, lbs gradient) + locally_rigid_fn + mesh_laplacian_smoothing('cot'); "
+                 + ("one hipGraph replay per step" if g2 is not None else "eager launches"))
+        ops.invalidate_setups()
 
-    # ---- per-kernel durations (hipEvents on the launch stream) over the same K steps
+    # ---- per-kernel durations (hipEvents on the launch stream) over the same K steps, eager launches of the headline step
+    eager_fn, _ = make_step(headline_shape, use_graph=False)
+    kern = kernel_profile(ctx, eager_fn, a.steps)
     roof = None
-    kern = {}
-    lib = _lib.lib()
     if rank == 0:
-        lib.acfm_prof_enable(1)
-    for _ in range(a.steps):  # every rank runs the same steps (the all-reduce is collective)
-        step()
-    fence()
-    if rank == 0:
-        ms = (ctypes.c_float * 24)()
-        cnt = (ctypes.c_int * 24)()
-        _lib.check(lib.acfm_prof_collect(ms, cnt, 24), "acfm_prof_collect")
-        lib.acfm_prof_enable(0)
-        for i in range(24):
-            if cnt[i]:
-                kern[lib.acfm_prof_name(i).decode()] = dict(avg_us=1e3 * ms[i] / cnt[i], launches=cnt[i],
-                                                            us_per_step=1e3 * ms[i] / a.steps)
-        dom = max(kern, key=lambda k: kern[k]["us_per_step"])
-        # ALGORITHMIC bytes per launch, fp32:
-        alg = {
-            # read verts 12V + cam 28 (+ faces 12F shared, once per batch); write mask 4H^2 + nearest face id 8H^2
-            "k_raster_fwd<K,soft>": N * (12 * H * H + 12 * V + 28) + 12 * F,
-            # read grad 4H^2 + mask 4H^2 + K-th key 8H^2; write grad_verts 12V + grad_cam 28
-            "k_sil_bwd": N * (16 * H * H + 12 * V + 28),
-            # read atlas 12FR^2 ; write image 12H^2 + sil 4H^2 + face id 8H^2
-            "k_raster_fwd<1,tex>": N * (24 * H * H + 12 * F * R * R + 12 * V + 28),
-            "k_tex_bwd": N * (12 * H * H + 4 * H * H + 12 * F * R * R),
-            "k_mask_losses": N * 12 * H * H, "k_mask_losses_bwd": N * 16 * H * H,
-        }
-        if cfg5:   # half storage, int32 nearest-face plane, fused losses (SURVEY 8d with the halved terms)
-            alg = {
-                # write mask 2H^2 + id 4H^2, read gt 2H^2 + edt 2H^2, verts 12V, cam 28 (+ faces 12F once)
-                "k_raster_fwd<K,soft>": N * (10 * H * H + 12 * V + 28) + 12 * F,
-                # read mask 2H^2 + gt 2H^2 + edt 2H^2 (no mask gradient: formed in the kernel), write grads 12V + 28
-                "k_sil_bwd": N * (6 * H * H + 12 * V + 28),
-                # read atlas 6FR^2 + reference image 6H^2 + mask 2H^2; write image 6H^2 + sil 2H^2 + id 4H^2
-                "k_raster_fwd<1,tex>": N * (20 * H * H + 6 * F * R * R + 12 * V + 28),
-                # read image 6H^2 + reference 6H^2 + mask 2H^2; write the float atlas gradient 12FR^2
-                "k_tex_bwd": N * (14 * H * H + 12 * F * R * R),
-            }
-        ab = alg.get(dom, 0)
-        ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
-        # the committed measurement of the same workload (rocprofv3 --pmc, separate passes) is quoted
-        traffic, traffic_src, pmk = None, None, None
-        for tag in ("r02", "r01"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)))
-                w = pm["workload"]
-                same = (w["frames"], w["img"], w["K"], w.get("mesh", "bird"), w.get("storage", "f32")) == \
-                       (N, H, 20, "horse_subdiv1" if cfg5 else "bird", "f16" if cfg5 else "f32")
-                if same and dom in pm["kernels"]:
-                    pmk = pm["kernels"][dom]
-                    traffic = pmk["fetch_bytes"] + pmk["write_bytes"]
-                    traffic_src = "profiles/%s_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE per launch, own --pmc passes)" % tag
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
-        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=ab, avg_launch_us=round(kern[dom]["avg_us"], 2))
-        if pmk and pmk.get("valu_insts"):
-            # What limits the kernel is VALU issue, not HBM.  Issue rates measured on this part with independent
-            # instruction streams at 4 waves per SIMD (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt):
-            # fp32 add / mul / fma, integer add, and: 1.21 ns per wave-instruction and SIMD (844 G/s on 1024 SIMDs);
-            # selects, compares, min / max / med3, shifts, 64-bit moves, DPP, packed fp32: 1.75-1.95 ns (525-585 G/s);
-            # rcp / exp / sqrt: 3.5 ns (293 G/s).  The raster kernels' stream is mostly the second class (the sorted
-            # insertion is one 64-bit compare + six selects per slot), so its ceiling lies between the two figures.
-            rate = pmk["valu_insts"] / (kern[dom]["avg_us"] * 1e-6)
-            v = dict(insts_per_launch=pmk["valu_insts"], achieved_ginst_s=round(rate / 1e9, 1),
-                     full_rate_ginst_s=844.4, half_rate_class_ginst_s=572.7,
-                     frac_of_full_rate=round(rate / 844.4e9, 4), frac_of_half_rate_class=round(rate / 572.7e9, 4),
-                     source=traffic_src.split(" ")[0] + " (SQ_INSTS_VALU), profiles/r02_valu_rates.txt (rates)")
-            if pmk.get("active_inst_valu") and pmk.get("grbm_gui_active"):
-                # SQ_ACTIVE_INST_VALU counts quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                v["valu_busy"] = round(pmk["active_inst_valu"] * 4 / (1024 * pmk["grbm_gui_active"] / 8), 4)
-            if pmk.get("thread_cycles_valu") and pmk.get("active_inst_valu"):
-                v["lanes_active"] = round(pmk["thread_cycles_valu"] / (64 * pmk["active_inst_valu"]), 4)
-            roof["valu"] = v
-            v["valu_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): an estimate, a few % above 1 when saturated"
-            roof["limiter"] = {
-                "k_sil_bwd": "VALU issue (per pixel x face pair: membership test key <= kth, exact edge distance again, its "
-                             "backward to three vertices, 4 DPP row shifts per gradient component before the LDS accumulators)",
-            }.get(dom, "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)")
-        if traffic:   # what the kernel actually moves (the API's K int64 ids per pixel dominate): context, not `achieved`
-            moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
+        roof = roofline_of(kern, algorithmic_bytes(N, H, V, F, R, half=cfg5),
+                           (N, H, 20, "horse_subdiv1" if cfg5 else "bird", "f16" if cfg5 else "f32"))
 
-    # ---- CPU baseline: the oracle on this box's host cores, bounded sample (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle on this box's host cores, bounded samples (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import oracle as O
+        P_np = solver.solve_matrix().detach().cpu().numpy()
+        d_np, c_np = delta0.cpu().numpy(), cams0.cpu().numpy()
+        at_np = atlas.detach().cpu().numpy()
+        gt_np, edt_np, bds_np, img_np = gt_mask.cpu().numpy(), edt.cpu().numpy(), bds.cpu().numpy(), imgs_gt.cpu().numpy()
         verts_np = solver(delta0).detach().cpu().numpy()
-        cams_np = cams0.cpu().numpy()
         gmask = np.sign(np.random.default_rng(0).standard_normal((N, H, H))).astype(np.float32) / (H * H)
-        # host-core share of a one-GPU box (the pool's guidance: 16 workers per GPU)
-        cores = min(16, len(os.sched_getaffinity(0)))
-        cores = O.set_threads(cores)
 
-        def cpu_frames(k):
-            t = time.perf_counter()
-            O.sil_render_backward(verts_np[:k], f_np, cams_np[:k], H, gmask[:k])
-            return time.perf_counter() - t
-        t1 = cpu_frames(1)
-        k = int(max(1, min(N, a.cpu_seconds / max(t1, 1e-3))))
-        tk = cpu_frames(k)
-        cpu = dict(value=round(k / tk, 3), unit="frames/s", cores=cores, kind="port",
-                   sample="oracle silhouette render K=20 + backward, %d frame(s) @%dx%d, OpenMP over rows" % (k, H, H))
+        def full(k):     # the headline step, term for term (oracle.headline_step), on k frames
+            O.headline_step(v_np, P_np, d_np[:k], f_np, c_np[:k], at_np[:k], gt_np[:k], edt_np[:k], bds_np[:k], img_np[:k], H,
+                            weights=(1.0, 0.1, 0.1, 0.5))
 
-    if rank == 0:
-        out = {
-            "metric": "frames/s differentiable render+bwd, 5k-face mesh @512^2, 16 frames/GPU (config 5 shard)" if cfg5 else
-                      "frames/s differentiable render+bwd, 642-vert mesh @256^2, batch=64",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (half storage)" if cfg5 else "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 5, one GPU's share: subdivided horse template (%d v / %d f), %d frames/GPU "
-                                    "@%dx%d, half storage with fp32 loss sums, deform apply + fused soft silhouette K=20 / L1 / "
-                                    "IoU / EDT + boundary loss + fused atlas texture render / MSE, fwd+bwd" % (V, F, N, H, H))
-                       if cfg5 else
-                       "CUB bird template (642 v / 1280 f), %d frames/GPU @%dx%d, deform apply + "
-                       "soft silhouette K=20 + L1/IoU/EDT + boundary loss%s, fwd+bwd" %
-                       (N, H, H, " + atlas texture render/MSE" if a.tex else ""),
-                       "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
-                       "sharding": "frames over ranks; all-reduce of shared mean-shape grad"},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
-        }
-        out["launch"] = "one hipGraph replay per step (+ the RCCL all-reduce)" if use_graph else "eager (one Python launch per kernel)"
-        if graph_note:
-            out["launch_note"] = graph_note
-        if dt_other:
-            out["hipgraph_replay" if not use_graph else "eager_launch"] = {
-                "value": round(world * N * a.steps / dt_other, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_other / a.steps, 4)}
-        if dt_render:
-            out["render_only"] = {
-                "value": round(world * N * a.steps / dt_render, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_render / a.steps, 4),
-                "note": "soft-silhouette render K=20 (pix_to_face [N,H,W,20] as the default lazy tensor) + backward to "
-                        "vertices and cameras only; eager launches"}
-        if dt_full:
-            out["survey_8d_step"] = {
-                "value": round(world * N * a.steps / dt_full, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_full / a.steps, 4),
-                "note": "headline step + per-step factorisation of the deformation system with learned handle weights "
-                        "(cot Laplacian, fp64 Cholesky, lbs gradient) + locally_rigid_fn + mesh_laplacian_smoothing('cot'); "
-                        + full_mode}
-        if dt_fused:
-            out["fused_render_loss"] = {
-                "value": round(world * N * a.steps / dt_fused, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_fused / a.steps, 4),
-                "note": "same step, silhouette losses and the masked texture MSE fused into the raster kernels "
-                        "(NeuralRenderer.forward_silhouette_losses / forward_texture_mse: acfm_sil_loss_*, acfm_tex_mse_*)"}
-        if lbs_info:
-            out["learn_lbs_step"] = lbs_info
-        if dt_det:
-            out["deterministic_backward"] = {
-                "value": round(world * N * a.steps / dt_det, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_det / a.steps, 4),
-                "note": "same step with _lib.raster_tuning(deterministic=True): the silhouette backward accumulates in "
-                        "2^-36 fixed point (int64 atomics), gradients bit-identical from run to run"}
-        if dt_lean:
-            out["all_slots_stored"] = {
-                "value": round(world * N * a.steps / dt_lean, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * dt_lean / a.steps, 4),
-                "note": "NeuralRenderer(pix_to_face_slots=20): all 20 planes of pix_to_face written by the render "
-                        "(the default returns the same [N,H,W,20] int64 tensor lazily: nearest-face plane written, "
-                        "the other planes rendered when first touched -- never, in this step)"}
-        if cpu:
-            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        def ren(k):      # the metric string taken literally: silhouette render K=20 + backward
+            O.sil_render_backward(verts_np[:k], f_np, c_np[:k], H, gmask[:k])
+        cpu = cpu_legs(a, full, N,
+                       "headline step (deform apply + silhouette K=20 + l1/edt + boundary loss + atlas texture + MSE, fwd+bwd) @%dx%d" % (H, H),
+                       "silhouette render K=20 + backward @%dx%d (what `render_only` times on the GPU)" % (H, H), ren)
+
+    if rank != 0:
+        return None
+    out = {
+        "metric": "frames/s differentiable render+bwd, 5k-face mesh @512^2, 16 frames/GPU (config 5 shard)" if cfg5 else
+                  "frames/s differentiable render+bwd, 642-vert mesh @256^2, batch=64",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (half storage)" if cfg5 else "f32", "data": "synthetic",
+        "config": {"workload": ("BASELINE config 5, one GPU's share: subdivided horse template (%d v / %d f), %d frames/GPU "
+                                "@%dx%d, half storage with fp32 loss sums, deform apply + fused soft silhouette K=20 / L1 / "
+                                "IoU / EDT + boundary loss + fused atlas texture render / MSE, fwd+bwd" % (V, F, N, H, H))
+                   if cfg5 else
+                   "CUB bird template (642 v / 1280 f), %d frames/GPU @%dx%d, %sdeform apply + "
+                   "soft silhouette K=20 + L1/IoU/EDT + boundary loss%s, fwd+bwd" %
+                   (N, H, H, "per-step factorisation of the deformation system (lbs + mean shape learned) + " if headline_shape else "",
+                    " + atlas texture render/MSE" if a.tex else ""),
+                   "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
+                   "shared_parameters": "lbs + mean shape" if headline_shape else "mean shape",
+                   "sharding": ("frames over ranks; ONE all-reduce of the pre-solve sums [G = sum g delta^T | sum g | loss] (%d bytes), "
+                                "d lbs finished on every rank by the solve's backward" % ex.bytes) if headline_shape else
+                               "frames over ranks; all-reduce of shared mean-shape grad"},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+    }
+    out["launch"] = ("one hipGraph replay per step (+ the RCCL all-reduce%s)" % (" + the solve's backward" if headline_shape else "")) \
+        if graphed else "eager (one Python launch per kernel)"
+    if world > 1 and headline_shape:
+        out["scaling_note"] = ("per-GPU work of this step includes the per-step factorisation (lbs learned); the like-for-like "
+                               "1-GPU figure is `shared_shape_step` of the --gpus 1 line, not its `value` (fixed handle weights)")
+    if ctx.graph_note:
+        out["launch_note"] = ctx.graph_note
+    out.update(legs)
+    if cpu:
+        out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if "render_only" in cpu and "render_only" in legs:
+            out["gpu_over_cpu_render_only"] = round(legs["render_only"]["value"] / cpu["render_only"]["value"], 1)
+    return out
+
+
+# ====================================================================================================== config 3
+def run_config3(ctx):
+    """BASELINE.json configs[2]: test-time refinement of a 32-frame horse clip @256^2 (multiframe/nnutils/predictor.py:
+    287-349): one step = ONE Adam iteration over the clip -- render, l1 + edt + boundary losses, backward to handle offsets
+    and cameras, Adam update -- replayed from a hipGraph.  Clips are independent: with --gpus N every rank refines its own
+    clip, there is no exchange ("replicas only")."""
+    a, rank, world, dev = ctx.a, ctx.rank, ctx.world, ctx.dev
+    from acfm_video_3d_reconstruction_amd import image_utils as IU, ops
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.refine import ClipRefiner
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
+    N, H, Kh = a.frames or 32, a.img or 256, a.handles
+    m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
+    v_np, f_np = m["horse_v"], m["horse_f"]
+    V, F = v_np.shape[0], f_np.shape[0]
+    rng = np.random.default_rng(3000 + rank)
+    cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v_np).max())), device=dev)
+    faces = torch.tensor(f_np, device=dev)[None].repeat(N, 1, 1).contiguous()
+    solver = DeformSolver(torch.tensor(v_np, device=dev), faces[0], torch.tensor(fps_lbs_logits(v_np, Kh), device=dev))
+    ren = NeuralRenderer(H)
+    with torch.no_grad():
+        gt, _ = ren(solver(torch.tensor(rng.normal(0, 0.05, (N, Kh, 3)).astype(np.float32), device=dev)), faces, cams)
+        gt = (gt > 0.5).float()
+    edt = IU.compute_dt(gt, norm=False)[:, None].contiguous()
+    bds = IU.compute_boundaries(gt)[:, :1000].contiguous()
+
+    def refiner(capturable):
+        return ClipRefiner(ren, solver, torch.zeros(N, Kh, 3, device=dev), cams, faces, gt, edt, bds, optimize_camera=True,
+                           capturable=capturable, log_len=a.warmup + a.steps + 8)
+    r = refiner(not a.eager)
+    graphed = False
+    if not a.eager:
+        try:
+            r.capture(3)
+            graphed = True
+        except Exception as exc:
+            torch.cuda.synchronize()
+            ctx.graph_note.append("refinement iteration: capture failed (%s: %s), eager launch instead" % (type(exc).__name__, str(exc)[:200]))
+            r = refiner(False)
+    dt = ctx.time_steps(r.step, a.warmup, a.steps)
+    hist = r.history()
+    legs = {}
+    if not a.headline_only:
+        r2 = refiner(False)
+        legs["eager_launch" if graphed else "eager_again"] = ctx.leg(ctx.time_steps(r2.step, max(2, a.warmup // 2), a.steps), N, a.steps)
+    r3 = refiner(False)
+    kern = kernel_profile(ctx, r3.step, a.steps)
+    if rank != 0:
+        return None
+    roof = roofline_of(kern, algorithmic_bytes(N, H, V, F, 6), (N, H, 20, "horse", "f32"))
+    cpu = None
+    if world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        verts_np = solver(torch.zeros(N, Kh, 3, device=dev)).cpu().numpy()
+        c_np, gt_np, edt_np = cams.cpu().numpy(), gt.cpu().numpy(), edt.cpu().numpy()
+
+        def it(k):   # the raster part of one iteration: render + d(l1 + 0.1 edt)/d mask back to vertices and cameras
+            O.sil_render_backward(verts_np[:k], f_np, c_np[:k], H,
+                                  lambda mk, p2f: ((np.sign(mk - gt_np[:k]) + 0.1 * edt_np[:k, 0]) / (k * H * H)).astype(np.float32))
+        cpu = cpu_legs(a, it, N, "one refinement iteration's render + silhouette-loss backward (no boundary term, no Adam) @%dx%d" % (H, H))
+    out = {
+        "metric": "frames/s differentiable render+bwd per refinement iteration, horse clip of 32 frames @256^2 (config 3)",
+        "value": round(world * N * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: horse template (%d v / %d f), %d-frame clip @%dx%d, ONE Adam iteration of the "
+                               "test-time refinement (predictor.py:301-349): deform apply + soft silhouette K=20 + l1 / edt / boundary "
+                               "losses + backward to handle offsets and cameras + fused Adam update" % (V, F, N, H, H),
+                   "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
+                   "sharding": "replicas only: every rank refines its own clip, no exchange"},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        "launch": "one hipGraph replay per iteration" if graphed else "eager (one Python launch per kernel)",
+        "loss_first_last": [round(hist[0], 6), round(hist[-1], 6)] if hist else None,
+        "library_kernels_us_per_iteration": round(sum(k["us_per_step"] for k in kern.values()), 1),
+    }
+    if ctx.graph_note:
+        out["launch_note"] = ctx.graph_note
+    out.update(legs)
+    if cpu:
+        out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+    return out
+
+
+# ====================================================================================================== config 4
+def run_config4(ctx):
+    """BASELINE.json configs[3], one GPU's share: 32 frames @256^2 with horse / cow / bird interleaved (frame n renders
+    template n % 3: per-mesh faces AND vertices in one launch), each template with its OWN learned handle weights and mean
+    shape; silhouette + boundary + texture losses; ONE exchange per step for the three templates
+    (SharedShapeExchange.reduce_many: [G_h | sum g_h | loss | G_c | sum g_c | G_b | sum g_b])."""
+    a, rank, world, dev = ctx.a, ctx.rank, ctx.world, ctx.dev
+    from acfm_video_3d_reconstruction_amd import ops
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.sharding import SharedShapeExchange
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits, make_cams
+    N, H, Kh, R = a.frames or 32, a.img or 256, a.handles, 6
+    m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
+    names = ("horse", "cow", "bird")
+    rng = np.random.default_rng(4000 + rank)
+    which = np.arange(N) % 3
+    V, F = m["horse_v"].shape[0], m["horse_f"].shape[0]
+    exs, deltas, idxs, gt_deltas = [], [], [], []
+    for t, name in enumerate(names):
+        v_np, f_np = m[name + "_v"], m[name + "_f"]
+        assert v_np.shape[0] == V and f_np.shape[0] == F
+        mean_t = torch.nn.Parameter(torch.tensor(v_np, device=dev))
+        lbs_t = torch.nn.Parameter(torch.tensor(fps_lbs_logits(v_np, Kh), device=dev))
+        exs.append(SharedShapeExchange(DeformSolver(mean_t, torch.tensor(f_np, device=dev), lbs_t)))
+        idx = np.nonzero(which == t)[0]
+        idxs.append(idx)
+        deltas.append(torch.tensor(rng.normal(0, 0.02, (len(idx), Kh, 3)).astype(np.float32), device=dev, requires_grad=True))
+        gt_deltas.append(torch.tensor(rng.normal(0, 0.03, (len(idx), Kh, 3)).astype(np.float32), device=dev))
+    inv = torch.tensor(np.argsort(np.concatenate(idxs)), device=dev)             # template-major -> frame order
+    faces = torch.stack([torch.tensor(m[names[t] + "_f"], device=dev) for t in which]).contiguous()     # [N,F,3] per mesh
+    ext = np.array([float(np.abs(m[names[t] + "_v"]).max()) for t in which])
+    cams0 = np.stack([make_cams(1, rng, extent=e)[0] for e in ext])
+    cams = torch.tensor(cams0, device=dev, requires_grad=True)
+    ren = NeuralRenderer(H)
+    with torch.no_grad():
+        gt_v = torch.cat([ex.solver(d) for ex, d in zip(exs, gt_deltas)])[inv]
+        gt_cams = cams.detach().clone()
+        gt_cams[:, 1:3] += torch.tensor(rng.uniform(-0.03, 0.03, (N, 2)).astype(np.float32), device=dev)
+        gt_mask, _ = ren(gt_v, faces, gt_cams)
+        gt_mask = (gt_mask > 0.5).float()
+    edt, bds = edt_and_boundaries(gt_mask)
+    imgs_gt = torch.tensor(rng.uniform(0, 1, (N, 3, H, H)).astype(np.float32), device=dev)
+    atlas = torch.tensor(rng.uniform(0, 1, (N, F, R, R, 3)).astype(np.float32), device=dev, requires_grad=True)
+    seed = torch.ones((), device=dev)
+    sides = [torch.cuda.Stream(device=dev) for _ in exs]
+
+    def compute():
+        # the three templates' factorisations are independent latency-bound chains (a few CUs each, ~170 us): forked onto
+        # three streams (parallel branches of the captured graph) they cost one, not three
+        cur = torch.cuda.current_stream(dev)
+        preds = []
+        for ex, d, st in zip(exs, deltas, sides):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                preds.append(ex.apply(d))          # cot Laplacian + factorisation + deformation apply on (P, mean) leaves
+        for p_, st in zip(preds, sides):
+            cur.wait_stream(st)
+            p_.record_stream(cur)
+        pred_v = torch.cat(preds)[inv]
+        mask, p2f = ren(pred_v, faces, cams)
+        sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)
+        bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
+        tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)
+        tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)
+        total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
+        leaves = [x for ex in exs for x in (ex._P_leaf, ex._mean_leaf)]
+        g = torch.autograd.grad(total, deltas + [cams, atlas] + leaves, grad_outputs=seed)
+        gl = g[len(deltas) + 2:]
+        for t, ex in enumerate(exs):
+            ex.pack(gl[2 * t], gl[2 * t + 1], extra_scalars=total.detach().reshape(1) if t == 0 else None)
+        return total.detach(), g[:len(deltas) + 2]
+
+    def exchange():
+        SharedShapeExchange.reduce_many(exs)     # ONE all-reduce for the three templates
+        cur = torch.cuda.current_stream(dev)
+        for ex, st in zip(exs, sides):           # the three solve backwards side by side as well
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ex.unpack()
+        for st in sides:
+            cur.wait_stream(st)
+
+    def eager():
+        outs = compute()
+        exchange()
+        return outs
+    g, outs = (None, None) if a.eager else ctx.capture(compute, "config-4 step")
+
+    def replay():
+        g.replay()
+        exchange()
+        return outs
+    step = replay if g is not None else eager
+    dt = ctx.time_steps(step, a.warmup, a.steps)
+    ops.invalidate_setups()
+    legs = {}
+    if not a.headline_only and g is not None:
+        legs["eager_launch"] = ctx.leg(ctx.time_steps(eager, max(2, a.warmup // 2), a.steps), N, a.steps)
+    kern = kernel_profile(ctx, eager, a.steps)
+    if rank != 0:
+        return None
+    roof = roofline_of(kern, algorithmic_bytes(N, H, V, F, R), (N, H, 20, "mixed", "f32"))
+    cpu = None
+    if world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        with torch.no_grad():
+            verts_np = torch.cat([ex.solver(d) for ex, d in zip(exs, deltas)])[inv].cpu().numpy()
+        c_np, gt_np, edt_np, f_all = cams.detach().cpu().numpy(), gt_mask.cpu().numpy(), edt.cpu().numpy(), faces.cpu().numpy()
+
+        def it(k):
+            O.sil_render_backward(verts_np[:k], f_all[:k], c_np[:k], H,
+                                  lambda mk, p2f: ((np.sign(mk - gt_np[:k]) + 0.1 * edt_np[:k, 0]) / (k * H * H)).astype(np.float32))
+        cpu = cpu_legs(a, it, N, "silhouette render K=20 + silhouette-loss backward of the mixed shard (no texture / boundary terms) @%dx%d" % (H, H))
+    nbytes = sum(ex.bytes for ex in exs) if world == 1 else exs[0].bytes
+    out = {
+        "metric": "frames/s differentiable render+bwd, mixed quadruped batch @256^2, 32 frames/GPU (config 4 shard)",
+        "value": round(world * N * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4, one GPU's share: horse / cow / bird templates interleaved (642 v / 1280 f each; "
+                               "'sheep' is not shipped by the reference), %d frames/GPU @%dx%d, lbs + mean shape of the three "
+                               "templates learned: 3 factorisations + deform apply + soft silhouette K=20 + L1/IoU/EDT + boundary loss "
+                               "+ atlas texture render/MSE, fwd+bwd" % (N, H, H),
+                   "frames_per_gpu": N, "img_size": H, "handles": Kh, "faces_per_pixel": 20,
+                   "sharding": "frames over ranks; ONE all-reduce of the three templates' pre-solve sums (%d bytes)" % nbytes},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        "launch": "one hipGraph replay per step (+ the RCCL all-reduce + three solve backwards)" if g is not None else "eager",
+    }
+    if ctx.graph_note:
+        out["launch_note"] = ctx.graph_note
+    out.update(legs)
+    if cpu:
+        out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+    return out
+
+
+def main():
+    a = parse()
+    ctx = Ctx(a)
+    if a.config == 3:
+        out = run_config3(ctx)
+    elif a.config == 4:
+        out = run_config4(ctx)
+    else:
+        out = run_config2_or_5(ctx)
+    if ctx.rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

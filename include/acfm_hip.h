@@ -215,9 +215,10 @@ size_t acfm_raster_workspace_bytes(int N, int V, int F, int H);
 
 /* Per-call launch tuning of the raster entry points (pure speed: results never depend on it, `flags` apart).
  * NULL = the defaults.  There is no process-global tuning state in the library.
- *   split_mode: the heaviest 8x8 blocks of a small launch are rendered by four workgroups each;
- *               < 0 automatic (decided on the device from the cost histogram; default -3),
- *               0 never, 1 always (for every launch size);
+ *   split_mode: the heaviest 8x8 blocks of a launch are rendered by four workgroups each (a launch lasts at least as
+ *               long as its longest block: all of a small launch's heavy blocks, the top few dozen of a large one);
+ *               < 0 automatic: decided on the device from the cost histogram, a block is split when its cost exceeds
+ *               (-split_mode / 4) x the mean work per wave slot (default -5: 1.25 x), 0 never, 1 always;
  *   grid_div:   workgroups per XCD group = entries / div for [0] the K-nearest forward, [1] the
  *               nearest-face (K = 1) forward, [2] the silhouette backward; 0 = default (4, 2, 4).
  *   flags:      bit 0 = deterministic silhouette backward: vertex gradients are accumulated in 64-bit fixed point
@@ -264,6 +265,19 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
                      float offset_z, void* mask /* [real] */, void* pix_to_face /* int64, or the int32 plane */,
                      uint64_t* kth, uint8_t* vis, void* ws, size_t ws_bytes, const AcfmRasterTuning* tuning,
                      void* stream);
+
+/* acfm_sil_forward for a silhouette render that a texture render of the same prediction follows (the reference's
+ * pair renderer(...) / tex_renderer(...), multiframe/main.py:620-626): besides its own outputs it stores the CONSTANT
+ * outputs of that texture render -- imgs 0, sil 0, pix_to_face -1, texel_idx -1 -- on the 8x8 blocks no face comes
+ * near (~80 % of a frame), into the caller's buffers for them; acfm_tex_forward(ws_ready = 3) on the same workspace then
+ * writes only the blocks with work.  Needs ACFM_RECORD_COVER in the tuning and float storage.  Same results as the
+ * plain pair; the constant stores drain behind the K-nearest walk instead of being 2/3 of the texture kernel. */
+int acfm_sil_forward_prefill(const float* verts_world, const int64_t* faces, const float* cams, int N,
+                             int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
+                             float offset_z, void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* ws,
+                             size_t ws_bytes, const AcfmRasterTuning* tuning, float* tex_imgs /* [N,3,H,H] */,
+                             float* tex_sil /* [N,H,H] */, int64_t* tex_pix_to_face /* [N,H,H,1] */,
+                             int32_t* tex_texel_idx /* [N,H,H] */, void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
@@ -318,6 +332,8 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
  * face setup are skipped and the blur-expanded boxes tightened by sqrt(ws_blur).
  * ws_ready == 2: that acfm_sil_forward ran with ACFM_RECORD_COVER (and the same tuning is passed here): the nearest
  * covering face of every pixel is read from the workspace, nothing is binned or walked.
+ * ws_ready == 3: as 2, and that render was acfm_sil_forward_prefill with THESE imgs / sil / pix_to_face / texel_idx
+ * buffers: the blocks no face comes near hold their constants already and are not written again.
  * atlas_batch: number of distinct atlases, atlas [atlas_batch,F,R,R,3]; mesh n samples atlas
  * n % atlas_batch (the trainer renders G camera hypotheses of every frame with the frame's one
  * texture, textures.repeat(G, ...) at main.py:627-636: atlas_batch = N / G spares the copies, and

@@ -183,7 +183,8 @@ def sil_render(verts, faces, cams, img_size, offset_z=0.0, K=SIL_K, sigma=SIL_SI
 
 def sil_render_backward(verts, faces, cams, img_size, grad_mask, offset_z=0.0, K=SIL_K,
                         sigma=SIL_SIGMA, blur=SIL_BLUR):
-    """Gradient of sum(mask * grad_mask) wrt verts [N,V,3] and cams [N,7].
+    """Gradient of sum(mask * grad_mask) wrt verts [N,V,3] and cams [N,7].  grad_mask: [N,H,W], or a callable
+    mask -> [N,H,W] (a loss on the rendered mask: one render serves the loss and its backward).
 
     Raster + blend backward in C (App-A.4/A.5); the index gather and the projection chain
     go through torch-CPU autograd in float64 (the reference relies on autograd there)."""
@@ -194,6 +195,8 @@ def sil_render_backward(verts, faces, cams, img_size, grad_mask, offset_z=0.0, K
     if faces_np.ndim == 2:
         faces_np = np.broadcast_to(faces_np, (N,) + faces_np.shape)
     mask, p2f, aux = sil_render(verts, faces, cams, img_size, offset_z, K, sigma, blur, True)
+    if callable(grad_mask):
+        grad_mask = grad_mask(mask, p2f)
     gd = sigmoid_alpha_blend_backward(p2f, aux["dists"], grad_mask, sigma)
     gfv = rasterize_backward_dists(aux["face_verts"], p2f, gd).reshape(N, -1, 3, 3)
     g_ndc = np.zeros((N, V, 3), np.float64)
@@ -205,6 +208,46 @@ def sil_render_backward(verts, faces, cams, img_size, grad_mask, offset_z=0.0, K
     ndc = torch.stack([-proj[..., 0], -proj[..., 1], proj[..., 2] + EYE_Z], -1)
     (ndc * torch.from_numpy(g_ndc)).sum().backward()
     return tv.grad.numpy().astype(np.float32), tc.grad.numpy().astype(np.float32), mask, p2f
+
+
+def headline_step(mean_v, P, delta, faces, cams, atlas, gt, edt, bds, img, img_size, weights=(1.0, 0.1, 0.1, 0.5)):
+    """The benchmark's headline step on the CPU, term for term (bench.py `compute`; BASELINE.md section 3's "full step"):
+    deformation apply v = mean + P delta (main.py:586-609 collapsed) -> soft-silhouette render K=20 -> l1 + edt losses
+    -> boundary loss -> atlas-texture render + masked MSE -> backward to handle offsets, cameras, mean shape and atlas.
+    weights = (l1, edt, bds, texture mse); total = mean_n(l1 + w_e edt + w_b bds) + w_t mean_n(mse).
+    numpy / torch-CPU float32 in, -> dict(total, g_delta, g_cams, g_mean, g_atlas, mask, p2f)."""
+    w_l1, w_e, w_b, w_t = weights
+    H = img_size
+    mean_v, P, delta, cams = _f32(mean_v), _f32(P), _f32(delta), _f32(cams)
+    N = delta.shape[0]
+    verts = (mean_v[None] + np.einsum("vk,nkc->nvc", P, delta)).astype(np.float32)
+    gt, edt = _f32(gt), _f32(edt).reshape(N, H, H)
+    out = {}
+
+    def grad_of_mask(mask, p2f):
+        out["l1"] = np.abs(mask - gt).reshape(N, -1).mean(1)
+        out["edt"] = (edt * mask).reshape(N, -1).mean(1)
+        return ((w_l1 * np.sign(mask - gt) + w_e * edt) / (N * H * H)).astype(np.float32)
+    gv, gc, mask, p2f = sil_render_backward(verts, faces, cams, H, grad_of_mask)
+    # boundary loss on the projected vertices (loss_utils.py:204-237), gradient by torch-CPU autograd
+    tv = torch.tensor(verts, requires_grad=True)
+    tc = torch.tensor(cams, requires_grad=True)
+    faces_t = torch.as_tensor(np.broadcast_to(np.asarray(faces), (N,) + np.asarray(faces).shape[-2:]).copy())
+    bdt = bds_loss(project_torch(tv, tc)[..., :2], torch.as_tensor(_f32(bds)), faces_t, torch.from_numpy(p2f), reduce=False)
+    (w_b * bdt.mean()).backward()
+    gv = gv + tv.grad.numpy()
+    gc = gc + tc.grad.numpy()
+    # texture branch on detached geometry (main.py:627-636, 655-662)
+    imgs, _, _, tidx = tex_render(verts, faces, cams, atlas, H)
+    m1 = gt[:, None]
+    diff = imgs * m1 - _f32(img) * m1
+    mse = (diff ** 2).reshape(N, -1).mean(1)
+    g_img = (w_t / N) * 2.0 * diff * m1 / (3 * H * H)
+    g_atlas = tex_render_backward_atlas(tidx, g_img, np.asarray(atlas).shape)
+    out.update(total=float((w_l1 * out["l1"] + w_e * out["edt"] + w_b * bdt.detach().numpy()).mean() + w_t * mse.mean()),
+               g_delta=np.einsum("vk,nvc->nkc", P, gv).astype(np.float32), g_cams=gc, g_mean=gv.sum(0), g_atlas=g_atlas,
+               mask=mask, p2f=p2f, bdt=bdt.detach().numpy(), mse=mse)
+    return out
 
 
 def tex_render(verts, faces, cams, atlas, img_size, offset_z=0.0, sigma=1e-4, gamma=1e-4):

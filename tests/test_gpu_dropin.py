@@ -170,7 +170,7 @@ def test_data_parallel_replicas_and_gather(meshes):
     assert torch.equal(b, b0) and not p0.is_materialized
     b1 = dpb(proj, I["bds"], I["faces"], p2f, reduce=False)            # the gathered plain tensor (replica-local ids), as in main.py
     assert torch.equal(b1, b0)
-    (L.l1_loss(mask, I["gt"]) + 0.1 * b.mean()).backward()
+    (L.l1_loss(mask, I["gt"]) + 0.1 * b.mean()).backward(retain_graph=True)
     gv, gc = tv.grad.clone(), tc.grad.clone()
     tv.grad = tc.grad = None
     (L.l1_loss(m0, I["gt"]) + 0.1 * b0.mean()).backward()

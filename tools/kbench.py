@@ -27,7 +27,7 @@ def main():
     p.add_argument("--kout", type=int, default=0, help="1: only the nearest-face plane of pix_to_face is written")
     p.add_argument("--det", type=int, default=0, help="1: deterministic (fixed-point) silhouette backward")
     p.add_argument("--fused", type=int, default=0, help="1: the fused render+loss operator (acfm_sil_loss_*)")
-    p.add_argument("--split", type=int, default=-3, help="block splitting: < 0 automatic, 0 never, 1 always")
+    p.add_argument("--split", type=int, default=-5, help="block splitting: < 0 automatic, 0 never, 1 always")
     p.add_argument("--div", default="0,0,0", help="workgroups per group = entries / div: fwdK,fwd1,bwd (0 = default)")
     a = p.parse_args()
     dev = torch.device("cuda:0")
