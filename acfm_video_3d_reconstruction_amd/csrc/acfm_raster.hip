@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     {
       const float denom = area + ACFM_K_EPS;
       r.c = make_float4(z2, area, denom, recip_refined(denom));
-#if ACFM_EDGE_CONST
+#if ACFM_REC_EDGES
       // point_line_dist's own operations on (a, b) = (v0, v1), (v0, v2), (v1, v2): bax = bx - ax, l2 = bax bax + bay bay
       const float e01x = x1 - x0, e01y = y1 - y0, e02x = x2 - x0, e02y = y2 - y0, e12x = x2 - x1, e12y = y2 - y1;
       const float l01 = e01x * e01x + e01y * e01y, l02 = e02x * e02x + e02y * e02y, l12 = e12x * e12x + e12y * e12y;
@@ -682,7 +682,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   // iteration ahead was measured: +16 VGPRs, no change in time.)
   const int last = max(my_n - 1, 0);
 #ifndef ACFM_WALK_PREFETCH
-#define ACFM_WALK_PREFETCH 1
+#define ACFM_WALK_PREFETCH 0   // measured (64 frames, A/B on one box, twice): 192.7 / 193.4 us with it, 189.9 / 192.5 without
 #endif
 #if ACFM_WALK_PREFETCH
   // the list position of the NEXT iteration's candidate is read one iteration ahead: the walk's dependent chain per
@@ -741,6 +741,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
                                              fl_t* s_fl /* [FLCAP] */, float box_shrink, Walk&& walk) {
   if (t.empty) return;  // flagged by k_order: no face box near this block
 #if ACFM_MBOX_TEST
+  {
   float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
 #pragma unroll
   for (int i = 1; i < SETUP_SLICES; ++i) {
@@ -748,6 +749,7 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
     mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
   }
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
+  }
 #endif
   const unsigned long long lt = (1ull << t.lane) - 1ull;
   const int ctiles = (H + CTILE - 1) / CTILE, words = (F + 63) / 64;
@@ -892,7 +894,7 @@ __device__ __forceinline__ bool test_face_dist(float xf, float yf, const float4&
 // E1 = (|e12|^2, r12, degenerate flag, -).  Operation for operation point_line_dist / point_line_dist2 minus what does
 // not depend on the pixel; a face with a degenerate edge (flag) must take test_face_dist (its distance-to-endpoint branch).
 __device__ __forceinline__ bool test_face_dist_e(float xf, float yf, const float4& A, const float4& B, const float4& E0,
-                                                 const float4& E1, float blur, bool inside, Hit& h) {
+                                                 const float4& E1, float blur, bool inside, Hit& h, float* tpar = nullptr) {
   const float x0 = A.x, y0 = A.y, x1 = A.z, x2 = A.w, y1 = B.x, y2 = B.y;
   {
     const v2f ax = {x0, x0}, ay = {y0, y0}, bx = {A.z, A.w}, by = {B.x, B.y};
@@ -907,11 +909,13 @@ __device__ __forceinline__ bool test_face_dist_e(float xf, float yf, const float
     const v2f dx = qx - xf, dy = qy - yf;
     const v2f d = dx * dx + dy * dy;
     h.d01 = d.x; h.d02 = d.y;
+    if (tpar) { tpar[0] = t.x; tpar[1] = t.y; }
   }
   {
     const float bax = x2 - x1, bay = y2 - y1;
     float t = div_by(bax * (xf - x1) + bay * (yf - y1), E1.x, E1.y);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
+    if (tpar) tpar[2] = t;
     const float qx = x1 + t * bax, qy = y1 + t * bay;
     const float dx = qx - xf, dy = qy - yf;
     h.d12 = dx * dx + dy * dy;
@@ -1074,7 +1078,19 @@ template <int K, int B>   // block B = slots [4B, min(4B + 4, K)), called for B 
 __device__ __forceinline__ void shift_insert_block(unsigned long long (&key)[K], float (&q)[K], const unsigned long long x,
                                                    const float xq, int lim) {
   constexpr int LO = 4 * B, HI = (LO + 4 < K ? LO + 4 : K);
-  if (lim > LO) {   // (the list holds at most lim entries after this insertion: slots >= lim stay empty in every lane)
+#ifndef ACFM_INSERT_FILLTEST
+#define ACFM_INSERT_FILLTEST 0   // measured: 197.1 us with it, 197.5 without (A/B on one box): within noise, and it costs three registers
+#endif
+  bool beyond = lim <= LO;   // (the list holds at most lim entries after this insertion: slots >= lim stay empty in every lane)
+#if ACFM_INSERT_FILLTEST
+  // `lim` counts the faces WALKED, a loose bound on the faces a pixel KEPT: if slot LO - 1 is still empty in every
+  // inserting lane, every insertion point lies below this block and it would only shift empties into empties
+  // (one 32-bit compare -- the depth word of an empty slot is all ones, no depth >= 0 is -- instead of the block)
+  if constexpr (LO > 0) {
+    if (!beyond) beyond = __builtin_amdgcn_uicmp((unsigned)(key[LO - 1] >> 32), 0xffffffffu, 33 /* ICMP_NE */) == 0ull;
+  }
+#endif
+  if (!beyond) {
     DIAG_ADD(9, 1);
     unsigned long long pk = key_lt_mask(x, key[HI - 1]);
     if (pk == 0ull) return;            // no lane's element enters this block, hence none enters a lower one
@@ -1148,7 +1164,7 @@ __device__ __forceinline__ void bubble_insert(unsigned long long (&key)[K], floa
 // k_setup with the very operations the walk used to repeat for every (pixel, face) pair: two more 16-byte LDS
 // entries per candidate (32 B), ~33 instruction slots fewer per walk iteration, bit-identical values.
 #ifndef ACFM_EDGE_CONST
-#define ACFM_EDGE_CONST 0
+#define ACFM_EDGE_CONST 1
 #endif
 #ifndef ACFM_FWD_CAP
 #define ACFM_FWD_CAP (ACFM_EDGE_CONST ? 88 : RCAP)   // 96 B x 88 + sub-lists + id list + cull lists = 10 208 B <= 10 240
@@ -1908,6 +1924,10 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
     walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
       bool member = work && in_box;
       if (__ballot(member) == 0ull) return;
+#if ACFM_BWD_EDGE_GLOBAL
+      const FaceRec& grec = ws.rec[(size_t)t.n * F + cd.fid];
+      const float4 e0g = grec.e0, e1g = grec.e1;
+#endif
       const float4 A = cd.a, B = cd.b;
       Hit h;
       h.pz = 0.f; h.sd = 0.f; h.d01 = 0.f; h.d02 = 0.f; h.d12 = 0.f;
@@ -1918,7 +1938,18 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       member = member && (make_key(h.pz, cd.fid) <= kthkey);
       if (__ballot(member) == 0ull) return;
       float tpar[3] = {0.f, 0.f, 0.f};
+#if ACFM_BWD_EDGE_GLOBAL
+      // ACFM_BWD_EDGE_GLOBAL: the per-edge constants (|e|^2, refined 1/|e|^2) of the face from its record in memory
+      // (L2-resident: 128 B x 1280 faces per mesh) instead of recomputing them per pixel; requested before the depth
+      // stage so that its ~100 instructions cover the latency.  A face with a degenerate edge takes the unfactored path.
+      if (__ballot(e1g.z != 0.0f) != 0ull) {
+        if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h, tpar);
+      } else {
+        if (member) member = test_face_dist_e(t.xf, t.yf, A, B, e0g, e1g, blur, inside, h, tpar);
+      }
+#else
       if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h, tpar);
+#endif
       if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
       if (member) {
@@ -1984,7 +2015,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
 }
 
 template <class AccT>
-__global__ __launch_bounds__(RT) void k_sil_bwd(RasterWs ws, const void* __restrict__ mask,
+__global__ __launch_bounds__(RT, 6) void k_sil_bwd(RasterWs ws, const void* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
                                                  BwdGrad grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {

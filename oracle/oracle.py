@@ -210,19 +210,25 @@ def sil_render_backward(verts, faces, cams, img_size, grad_mask, offset_z=0.0, K
     return tv.grad.numpy().astype(np.float32), tc.grad.numpy().astype(np.float32), mask, p2f
 
 
-def headline_step(mean_v, P, delta, faces, cams, atlas, gt, edt, bds, img, img_size, weights=(1.0, 0.1, 0.1, 0.5)):
+def headline_step(mean_v, P, delta, faces, cams, atlas, gt, edt, bds, img, img_size, weights=(1.0, 0.1, 0.1, 0.5),
+                  render_verts=None):
     """The benchmark's headline step on the CPU, term for term (bench.py `compute`; BASELINE.md section 3's "full step"):
     deformation apply v = mean + P delta (main.py:586-609 collapsed) -> soft-silhouette render K=20 -> l1 + edt losses
     -> boundary loss -> atlas-texture render + masked MSE -> backward to handle offsets, cameras, mean shape and atlas.
     weights = (l1, edt, bds, texture mse); total = mean_n(l1 + w_e edt + w_b bds) + w_t mean_n(mse).
-    numpy / torch-CPU float32 in, -> dict(total, g_delta, g_cams, g_mean, g_atlas, mask, p2f)."""
+    numpy / torch-CPU float32 in, -> dict(total, g_delta, g_cams, g_mean, g_atlas, mask, p2f).
+    render_verts: deformed vertices to render instead of this function's own mean + P delta (the render is
+    discontinuous in its inputs: a parity test first compares the two deformations, then hands the product's float32
+    geometry over so that everything downstream is compared without depending on a last-bit coincidence)."""
     w_l1, w_e, w_b, w_t = weights
     H = img_size
     mean_v, P, delta, cams = _f32(mean_v), _f32(P), _f32(delta), _f32(cams)
     N = delta.shape[0]
     verts = (mean_v[None] + np.einsum("vk,nkc->nvc", P, delta)).astype(np.float32)
+    out = {"verts": verts}
+    if render_verts is not None:
+        verts = _f32(render_verts)
     gt, edt = _f32(gt), _f32(edt).reshape(N, H, H)
-    out = {}
 
     def grad_of_mask(mask, p2f):
         out["l1"] = np.abs(mask - gt).reshape(N, -1).mean(1)

@@ -244,3 +244,43 @@ def test_lazy_pix_to_face_made_inside_a_capture_refuses_to_form_outside_it(meshe
     np.testing.assert_array_equal(plane.cpu().numpy(), ref_p2f[..., 0])
     with pytest.raises(RuntimeError, match="hipGraph capture"):
         p2f[..., 1]
+
+
+def test_headline_step_vs_the_cpu_full_step(meshes):
+    """The benchmark's headline step (bench.py `compute`: deform apply -> silhouette -> L1/EDT -> boundary loss -> atlas
+    texture + MSE -> backward to handle offsets, cameras, mean shape, atlas) against oracle.headline_step, the CPU
+    restatement bench.py times as `cpu_baseline`: the two legs of `gpu_over_cpu` compute the same thing."""
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    N, H, R, Kh = 3, 96, 3, 8
+    I = _inputs(meshes, "bird", N, H, R, 77, d)
+    v_np, f_np = meshes["bird_v"], meshes["bird_f"]
+    rng = np.random.default_rng(78)
+    mean_p = torch.tensor(v_np, device=d, requires_grad=True)
+    solver = DeformSolver(torch.tensor(v_np, device=d), torch.tensor(f_np, device=d), torch.tensor(fps_lbs_logits(v_np, Kh), device=d))
+    delta = torch.tensor(rng.normal(0, 0.02, (N, Kh, 3)).astype(np.float32), device=d, requires_grad=True)
+    cams = torch.tensor(I["cams"], device=d, requires_grad=True)
+    atlas = torch.tensor(I["atlas_np"], device=d, requires_grad=True)
+    ren = NeuralRenderer(H)
+    pred_v = solver(delta, mean_override=mean_p)
+    mask, p2f = ren(pred_v, I["faces"], cams)
+    sil4 = L.fused_silhouette_losses(mask, I["gt"], I["edt"], raw=True)
+    bdt = L.bds_loss(ren.project_points(pred_v, cams), I["bds"], I["faces"], p2f, reduce=False)
+    tex, _, _ = ren(pred_v.detach(), I["faces"], cams, textures=atlas)
+    tmse = L.masked_texture_mse(tex, I["img"], I["gt"])
+    total = L.combine_losses([sil4, bdt, tmse], [1.0, 0.0, 0.0, 0.1, 0.1, 0.5])
+    g_delta, g_cams, g_mean, g_atlas = torch.autograd.grad(total, [delta, cams, mean_p, atlas])
+    P = solver.solve_matrix().detach().cpu().numpy()
+    ref = O.headline_step(v_np, P, delta.detach().cpu().numpy(), f_np, I["cams"], I["atlas_np"], I["gt_np"], I["edt_np"],
+                          I["bds_np"], I["img"].cpu().numpy(), H, weights=(1.0, 0.1, 0.1, 0.5),
+                          render_verts=pred_v.detach().cpu().numpy())
+    np.testing.assert_allclose(pred_v.detach().cpu().numpy(), ref["verts"], atol=1e-6)      # the two deformation applies
+    np.testing.assert_array_equal(p2f[..., 0].cpu().numpy(), ref["p2f"][..., 0])
+    np.testing.assert_allclose(float(total), ref["total"], rtol=1e-5)
+    for got, want, what in ((g_delta, ref["g_delta"], "delta"), (g_cams, ref["g_cams"], "cams"), (g_mean, ref["g_mean"], "mean"),
+                            (g_atlas, ref["g_atlas"], "atlas")):
+        got = got.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg=what)

@@ -479,6 +479,44 @@ def test_refinement_loop_reduces_the_loss(meshes):
     assert float((pv2 - pred_v).abs().max()) < 2e-2
 
 
+def test_refinement_loop_full_size_config3(meshes):
+    """BASELINE config 3 at its FULL size (the oracle comparison of one iteration runs at 4 frames @64^2 in
+    test_gpu_composed): a 32-frame horse clip @256^2, handle offsets + cameras, 12 Adam iterations with real EDTs and
+    boundary points.  Properties: the loss falls; with the deterministic silhouette backward the loop replayed from a
+    hipGraph (refine.ClipRefiner.capture) follows the eager loop to the summation order of the two small kernels that
+    still use float atomics (the boundary loss's per-vertex LDS sums, the per-mesh loss sums): 1e-5 after 12 steps."""
+    from acfm_video_3d_reconstruction_amd import _lib
+    from acfm_video_3d_reconstruction_amd import image_utils as IU
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    from acfm_video_3d_reconstruction_amd.refine import refine_clip
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _dev()
+    rng = np.random.default_rng(72)
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    N, H, Kh, iters = 32, 256, 16, 12
+    cams = torch.tensor(make_cams(N, rng, extent=float(np.abs(v).max())), device=d)
+    faces = torch.tensor(f, device=d)[None].repeat(N, 1, 1)
+    solver = DeformSolver(torch.tensor(v, device=d), faces[0], torch.tensor(fps_lbs_logits(v, Kh), device=d))
+    r = NeuralRenderer(H)
+    with torch.no_grad():
+        gt, _ = r(solver(torch.tensor(rng.normal(0, 0.05, (N, Kh, 3)).astype(np.float32), device=d)), faces, cams)
+        gt = (gt > 0.5).float()
+    edt = IU.compute_dt(gt, norm=False)[:, None].contiguous()
+    bds = IU.compute_boundaries(gt)[:, :1000].contiguous()
+    assert bds.shape[1] >= 200 and float(bds[..., 2].sum()) > 0
+    z = torch.zeros(N, Kh, 3, device=d)
+    with _lib.raster_tuning(deterministic=True):
+        pv, cam, delta, hist = refine_clip(r, solver, z, cams, faces, gt, edt, bds, num_optim_iter=iters, optimize_camera=True)
+        pv2, cam2, delta2, hist2 = refine_clip(r, solver, z, cams, faces, gt, edt, bds, num_optim_iter=iters,
+                                               optimize_camera=True, use_graph=True)
+    assert len(hist) == iters and hist[-1] < 0.8 * hist[0] and all(np.isfinite(hist))
+    assert pv.shape == (N, v.shape[0], 3) and torch.isfinite(pv).all()
+    np.testing.assert_allclose(hist2, hist, rtol=1e-5)
+    for a_, b_ in ((delta2, delta), (cam2, cam), (pv2, pv)):
+        assert float((a_ - b_).abs().max()) <= 1e-5 * max(1.0, float(b_.abs().max()))
+
+
 def test_hip_graph_capture_and_replay(meshes):
     """Every entry point is stream-ordered (no allocation or host sync inside): a render +
     loss + backward step captured into a hipGraph replays with identical results."""

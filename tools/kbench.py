@@ -28,9 +28,11 @@ def main():
     p.add_argument("--det", type=int, default=0, help="1: deterministic (fixed-point) silhouette backward")
     p.add_argument("--fused", type=int, default=0, help="1: the fused render+loss operator (acfm_sil_loss_*)")
     p.add_argument("--split", type=int, default=-5, help="block splitting: < 0 automatic, 0 never, 1 always")
+    p.add_argument("--prefill", type=int, default=1, help="0: the silhouette render does not pre-fill the texture render's empty blocks")
     p.add_argument("--div", default="0,0,0", help="workgroups per group = entries / div: fwdK,fwd1,bwd (0 = default)")
     a = p.parse_args()
     dev = torch.device("cuda:0")
+    ops.PREFILL_TEX[0] = bool(a.prefill)
     m = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
     v, f = m[a.mesh + "_v"], m[a.mesh + "_f"]
     for _ in range(a.subdiv):
