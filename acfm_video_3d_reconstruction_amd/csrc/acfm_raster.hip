@@ -2286,7 +2286,10 @@ __device__ __forceinline__ void divmod_small(int i, int w, float rw, int& q, int
   if (r >= w) { ++q; r -= w; }
 }
 constexpr int TEXG_MAX_R = 8;
-constexpr int TEXG_FPW = 4;      // faces per wave: their boxes, texel indices and gradients are loaded side by side
+#ifndef ACFM_TEXG_FPW
+#define ACFM_TEXG_FPW 4
+#endif
+constexpr int TEXG_FPW = ACFM_TEXG_FPW;      // faces per wave: their boxes, texel indices and gradients are loaded side by side
 constexpr int TEXG_U = 8;        // big boxes: 64 U pixels per round, all their loads in flight together
 // Upstream gradient of the rendered image: given ([N,3,H,H]) or, for the fused texture render + masked MSE, formed
 // on the fly from the rendered image, the reference image and mask and the per-mesh gradient of the loss --

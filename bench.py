@@ -455,9 +455,17 @@ def run_config2_or_5(ctx):
         ex.pack(gP, gmean, extra_scalars=total.detach().reshape(1))     # [G | sum g | loss] -> the exchange buffer (one cat)
         return total.detach(), g_delta, g_cams, None, g_atlas
 
-    def exchange_shape(outs):
+    unpack_graph = []
+
+    def exchange_shape(outs, graph_ok=True):
         ex.reduce()      # ONE all-reduce (RCCL) of ~49 KB
-        ex.unpack()      # d lbs = solve_backward(G) on every rank (acfm_deform_solve_backward), mean-shape gradient
+        # d lbs = solve_backward(G) on every rank (acfm_deform_solve_backward) + the mean-shape gradient: a second small
+        # hipGraph behind the collective when the step is replayed (the three launches + two copies are ~0.1 ms of host
+        # time when issued from Python)
+        if graph_ok and unpack_graph and unpack_graph[0] is not None:
+            unpack_graph[0].replay()
+        else:
+            ex.unpack()
 
     def make_step(shape_mode, ren=renderer, fused=False, use_graph=True):
         comp = (lambda: compute_shape(ren, fused)) if shape_mode else (lambda: compute(ren, fused))
@@ -470,14 +478,23 @@ def run_config2_or_5(ctx):
             # buffers (+ the solve's backward with --shared shape).
             g, outs = ctx.capture(comp, "shape step" if shape_mode else "step")
             if g is not None:
+                if shape_mode:
+                    ex.reduce()
+                    g2, _ = ctx.capture(ex.unpack, "solve backward behind the exchange")
+                    unpack_graph[:] = [g2]
+
                 def replay():
                     g.replay()
                     exch(outs)
                     return outs
                 return replay, True
+
         def eager():
             outs = comp()
-            exch(outs)
+            if shape_mode:
+                exchange_shape(outs, graph_ok=False)
+            else:
+                exch(outs)
             return outs
         return eager, False
 
@@ -848,8 +865,7 @@ def run_config4(ctx):
             ex.pack(gl[2 * t], gl[2 * t + 1], extra_scalars=total.detach().reshape(1) if t == 0 else None)
         return total.detach(), g[:len(deltas) + 2]
 
-    def exchange():
-        SharedShapeExchange.reduce_many(exs)     # ONE all-reduce for the three templates
+    def unpack_all():
         cur = torch.cuda.current_stream(dev)
         for ex, st in zip(exs, sides):           # the three solve backwards side by side as well
             st.wait_stream(cur)
@@ -857,12 +873,23 @@ def run_config4(ctx):
                 ex.unpack()
         for st in sides:
             cur.wait_stream(st)
+    unpack_graph = [None]
+
+    def exchange(graph_ok=True):
+        SharedShapeExchange.reduce_many(exs)     # ONE all-reduce for the three templates
+        if graph_ok and unpack_graph[0] is not None:
+            unpack_graph[0].replay()             # (a second small hipGraph behind the collective: the solve backwards)
+        else:
+            unpack_all()
 
     def eager():
         outs = compute()
-        exchange()
+        exchange(graph_ok=False)
         return outs
     g, outs = (None, None) if a.eager else ctx.capture(compute, "config-4 step")
+    if g is not None:
+        SharedShapeExchange.reduce_many(exs)
+        unpack_graph[0], _ = ctx.capture(unpack_all, "solve backwards behind the exchange")
 
     def replay():
         g.replay()
