@@ -70,7 +70,7 @@ constexpr int SETUP_LDS_TILES = 4096;  // counters kept in LDS up to 1024x1024 i
 constexpr int ENTRY_EMPTY = 1 << 30;   // order entry flag: no face box comes near this block
 constexpr int ENTRY_SPLIT = 1 << 29;   // order entry flag: a heavy block, rendered by four workgroups (one per 4x4 pixels)
 constexpr int ENTRY_FLAGS = ENTRY_EMPTY | ENTRY_SPLIT;
-constexpr int SPLIT_MAX_CLASS = 6;     // ... if their cost class is at most this (>= 80 face boxes)
+constexpr int SPLIT_MAX_CLASS = 4;     // ... if their cost class is at most this (>= 80 face boxes)
 constexpr int SETUP_LDS_MASK_BYTES = 64 * 1024;  // coarse masks built in LDS up to this size
 typedef unsigned short fl_t;  // face ids of one mesh (F <= ACFM_MAX_FACES = 65535)
 constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coarse tile, 4096 faces at a time)
@@ -270,12 +270,12 @@ int zero_async(void* p, size_t nbytes, hipStream_t st) {
 // The cost of a block is the face count of its 16x16 tile (k_setup); count 0 = no face box comes
 // near: the entry is flagged and the raster kernels write that block's zeros without looking at
 // the mesh at all.
-constexpr int NCLASS = 12;
-// (the four classes above 160 exist to ORDER the heaviest blocks: at 64 frames the blocks of >= 240 face boxes -- 89 of
-// 15 474, 3 % of the work -- start first and still run for the whole launch; see the split rule in k_order)
+constexpr int NCLASS = 10;
+// (the classes above 160 exist to ORDER the heaviest blocks: at 64 frames the blocks of >= 240 face boxes -- 89 of
+// 15 474, 3 % of the work -- start first and still run for the whole launch; see the split rule in k_order.  Every
+// class costs k_order a ballot per entry and pass: 12 classes measured 18.1 us per launch against 13.3 with 8)
 __device__ __forceinline__ int cost_class(int c) {
-  return c >= 320 ? 0 : c >= 280 ? 1 : c >= 240 ? 2 : c >= 200 ? 3 : c >= 160 ? 4 : c >= 112 ? 5 : c >= 80 ? 6 : c >= 56 ? 7
-       : c >= 36 ? 8 : c >= 20 ? 9 : c >= 1 ? 10 : 11;
+  return c >= 240 ? 0 : c >= 200 ? 1 : c >= 160 ? 2 : c >= 112 ? 3 : c >= 80 ? 4 : c >= 56 ? 5 : c >= 36 ? 6 : c >= 20 ? 7 : c >= 1 ? 8 : 9;
 }
 __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int H) {
   const int blocks = (H + RBLK - 1) / RBLK, tiles = (H + CNT_TILE - 1) / CNT_TILE;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
     // 195 us), so a block is split when its cost exceeds `ratio` x the group's mean work per wave slot (512 slots per
     // XCD at 16 one-wave workgroups per CU): a whole small launch, the top few dozen blocks of a large one.
     // split_mode < 0: ratio = -split_mode / 4 (default -5: 1.25).
-    const int mid[NCLASS] = {340, 300, 260, 220, 180, 136, 96, 68, 46, 28, 10, 0};
+    const int mid[NCLASS] = {290, 220, 180, 136, 96, 68, 46, 28, 10, 0};
     long total = 0;
     for (int c = 0; c < NCLASS; ++c) total += (long)s_hist[c] * mid[c];
     int max_class = -1;                      // split the classes 0 .. max_class

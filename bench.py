@@ -266,7 +266,14 @@ def roofline_of(kern, alg, workload_key):
         roof["limiter"] = {
             "k_sil_bwd": "VALU issue (per pixel x face pair: membership test key <= kth, exact edge distance again, its "
                          "backward to three vertices, 4 DPP row shifts per gradient component before the LDS accumulators)",
-        }.get(dom, "VALU issue (selects / compares of the sorted K-nearest insertion and the exact per-pixel tests)")
+        }.get(dom, "the launch's heaviest 8x8 blocks and VALU issue at once: per-block stamps (profiles/r03_tile_stamps.txt) show the "
+                   "blocks of ~300 candidate faces running from t = 0 to the end of the launch while the work per wave slot "
+                   "is 85-90 % of it; the four heaviest percent are split four ways (k_order).  Instruction diets moved the "
+                   "counters, not the time (DESIGN.md section 4, round 3)")
+        if dom == "k_raster_fwd<K,soft>" and traffic and traffic > 2 * ab:
+            roof["traffic_note"] = ("of the bytes moved, ~100 MB are the CONSTANT outputs of the texture render that follows (imgs / sil / "
+                                    "texel ids / face ids of the ~85 % empty blocks), stored by this kernel behind its walk "
+                                    "(acfm_sil_forward_prefill) instead of by k_tex_cover: writes moved between kernels, not re-reads")
     if traffic:   # what the kernel actually moves: context, not `achieved`
         moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
         roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))
