@@ -49,8 +49,14 @@ SIGNATURES = {
     "acfm_stream_capture_id": (_i, [_vp, _vp]),
     "acfm_sil_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                               _sz, _vp, _vp]),
-    "acfm_sil_forward_prefill": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
-                                      _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "acfm_sil_forward_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                 _sz, _vp, _vp, _vp]),
+    "acfm_sil_backward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
+                                  _sz, _i, _vp, _vp, _vp]),
+    "acfm_sil_loss_forward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "acfm_sil_loss_backward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _f, _vp,
+                                       _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "acfm_sil_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
                                _sz, _i, _vp, _vp]),
     "acfm_sil_loss_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
@@ -210,6 +216,20 @@ def with_cover(t, on):
     if bool(t.flags & 4) == bool(on):
         return t
     return RasterTuning(t.split_mode, (_i * 3)(*t.grid_div), (t.flags & ~4) | (4 if on else 0))
+
+
+class SilExtras(ctypes.Structure):
+    """AcfmSilExtras of include/acfm_hip.h (every field optional)."""
+    _fields_ = [("proj_xy", _vp), ("grad_proj_xy", _vp), ("tex_imgs", _vp), ("tex_sil", _vp), ("tex_pix_to_face", _vp),
+                ("tex_texel_idx", _vp)]
+
+
+def sil_extras(proj_xy=None, grad_proj_xy=None, prefill=None):
+    """-> (ctypes pointer, the structure to keep alive) for the `_ex` silhouette entry points; tensors or None."""
+    p = lambda t: None if t is None else t.data_ptr()
+    pf = prefill or (None, None, None, None)
+    e = SilExtras(p(proj_xy), p(grad_proj_xy), p(pf[0]), p(pf[1]), p(pf[2]), p(pf[3]))
+    return ctypes.byref(e), e
 
 
 _CONSTS = {}

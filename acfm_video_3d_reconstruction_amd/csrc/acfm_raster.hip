@@ -92,7 +92,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
                                                const float* __restrict__ cams, int V, int F, int H,
                                                float offset_z, int mode, float margin, RasterWs ws,
-                                               uint8_t* __restrict__ vis) {
+                                               uint8_t* __restrict__ vis, float* __restrict__ proj_xy) {
   extern __shared__ float s_v[];  // [V][3], then [tiles^2] int counters and this slice's mask words (if they fit)
   __shared__ float s_red[4][4];
   const int n = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
@@ -118,6 +118,9 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
     float px, py, pz;
     if (mode == 0) {
       project_point(cam, x[0], x[1], x[2], offset_z, px, py, pz);
+      // NeuralRenderer.project_points of the same vertices and cameras (nmr.py:127-129: proj_fn(...)[:, :, :2]) is
+      // this very (px, py): handed out on request (AcfmSilExtras.proj_xy) instead of being projected again
+      if (proj_xy && slice == 0) { proj_xy[((size_t)n * V + v) * 2] = px; proj_xy[((size_t)n * V + v) * 2 + 1] = py; }
       py = py * -1.0f;
     } else {
       px = x[0]; py = x[1]; pz = x[2];
@@ -2197,7 +2200,8 @@ __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ v
                                                      const float* __restrict__ cams,
                                                      float* gin /* NDC2: cleared after reading */, int V,
                                                      float* __restrict__ grad_verts,
-                                                     float* __restrict__ grad_cams) {
+                                                     float* __restrict__ grad_cams,
+                                                     const float* __restrict__ gproj = nullptr /* NDC modes: + [N,V,2] */) {
   __shared__ float s_red[4][7];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* c = cams + 7 * (size_t)n;
@@ -2213,10 +2217,14 @@ __global__ __launch_bounds__(TPB) void k_project_bwd(const float* __restrict__ v
       long long* g = reinterpret_cast<long long*>(gin) + ((size_t)n * V + v) * 2;
       gx = -((float)g[0] * FIX_INV); gy = -((float)g[1] * FIX_INV); gz = 0.f;
       g[0] = 0; g[1] = 0;
+      if (gproj) { gx += gproj[((size_t)n * V + v) * 2]; gy += gproj[((size_t)n * V + v) * 2 + 1]; }
     } else if (MODE == 1) {
       float* g = gin + ((size_t)n * V + v) * 2;
       gx = -g[0]; gy = -g[1]; gz = 0.f;
       g[0] = 0.f; g[1] = 0.f;   // the raster workspace's NDC-gradient scratch is left zeroed for the next backward
+      // the gradient of the projection the forward handed out (AcfmSilExtras.proj_xy: a second consumer of the same
+      // vertices and cameras, e.g. the boundary loss): one projection backward for both, no gradient sum afterwards
+      if (gproj) { gx += gproj[((size_t)n * V + v) * 2]; gy += gproj[((size_t)n * V + v) * 2 + 1]; }
     } else if (MODE == 2) {
       const float* g = gin + ((size_t)n * V + v) * 2;
       gx = g[0]; gy = g[1]; gz = 0.f;
@@ -2477,7 +2485,7 @@ void prof_end(hipStream_t st) {
 // ------------------------------------------------------------------------------- host side
 static int launch_setup(const float* verts, const int64_t* faces, const float* cams, int N, int V,
                         int F, int H, float offset_z, int mode, float blur, const RasterWs& ws,
-                        const Tune& tn, hipStream_t st, uint8_t* vis = nullptr) {
+                        const Tune& tn, hipStream_t st, uint8_t* vis = nullptr, float* proj_xy = nullptr) {
   const float margin = sqrtf(blur);
   const int tiles = (H + CNT_TILE - 1) / CNT_TILE;
   const int tt = tiles * tiles;                 // cost counters
@@ -2494,7 +2502,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   if (zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
-                     margin, ws, vis);
+                     margin, ws, vis, proj_xy);
   hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, tn.split);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
@@ -2656,8 +2664,11 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
                             void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
                             size_t ws_bytes, const AcfmRasterTuning* tuning, void* stream, bool fused,
                             const void* gt, const void* edt, int ref_batch, float* losses,
-                            float* pf_imgs = nullptr, float* pf_sil = nullptr, int64_t* pf_p2f = nullptr,
-                            int32_t* pf_tidx = nullptr) {
+                            const AcfmSilExtras* ex = nullptr) {
+  float* pf_imgs = ex ? ex->tex_imgs : nullptr;
+  float* pf_sil = ex ? ex->tex_sil : nullptr;
+  int64_t* pf_p2f = ex ? ex->tex_pix_to_face : nullptr;
+  int32_t* pf_tidx = ex ? ex->tex_texel_idx : nullptr;
   if (!verts_world || !faces || !cams || !mask || !pix_to_face || !wsp) return ACFM_E_BADARG;
   if (fused && (!losses || ref_batch <= 0 || N % ref_batch != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || K < 2 || K > ACFM_MAX_K || !(sigma > 0.f) || blur_radius < 0.f ||
@@ -2669,7 +2680,8 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   const RasterWs ws = carve_ws(wsp, N, V, F, H, tn.split);
   if (ws.bytes > ws_bytes) return ACFM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, tn, st, vis);
+  int rc = launch_setup(verts_world, faces, cams, N, V, F, H, offset_z, 0, blur_radius, ws, tn, st, vis,
+                        ex ? ex->proj_xy : nullptr);
   if (rc) return rc;
   FwdOut out = {};
   out.dbg = g_dbg;
@@ -2683,7 +2695,7 @@ static int sil_forward_impl(const float* verts_world, const int64_t* faces, cons
   out.sig_scale = 1.44269504088896341f / sigma;
   out.lrb = 1;
   if (tn.cover) out.cover_out = ws.cover;
-  if (pf_imgs) {   // all four or none; only with the cover plane (the texture render it prepares shades from it) and float storage
+  if (pf_imgs || pf_sil || pf_p2f || pf_tidx) {   // all four or none; only with the cover plane (the texture render it prepares shades from it) and float storage
     if (!pf_sil || !pf_p2f || !pf_tidx || !tn.cover || tn.f16) return ACFM_E_BADARG;
     out.pf_imgs = pf_imgs; out.pf_sil = pf_sil; out.pf_p2f = pf_p2f; out.pf_tidx = pf_tidx;
   }
@@ -2716,15 +2728,21 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
                           pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr);
 }
 
-int acfm_sil_forward_prefill(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
-                             int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
-                             void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
-                             size_t ws_bytes, const AcfmRasterTuning* tuning, float* tex_imgs, float* tex_sil,
-                             int64_t* tex_pix_to_face, int32_t* tex_texel_idx, void* stream) {
-  if (!tex_imgs || !tex_sil || !tex_pix_to_face || !tex_texel_idx) return ACFM_E_BADARG;
+int acfm_sil_forward_ex(const float* verts_world, const int64_t* faces, const float* cams, int N, int V,
+                        int F, int H, int K, int k_out, float blur_radius, float sigma, float offset_z,
+                        void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* wsp,
+                        size_t ws_bytes, const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream) {
   return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
-                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr,
-                          tex_imgs, tex_sil, tex_pix_to_face, tex_texel_idx);
+                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, false, nullptr, nullptr, 1, nullptr, extras);
+}
+
+int acfm_sil_loss_forward_ex(const float* verts_world, const int64_t* faces, const float* cams, const void* gt,
+                             const void* edt, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                             float blur_radius, float sigma, float offset_z, void* mask, void* pix_to_face,
+                             uint64_t* kth, uint8_t* vis, float* losses, void* wsp, size_t ws_bytes,
+                             const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream) {
+  return sil_forward_impl(verts_world, faces, cams, N, V, F, H, K, k_out, blur_radius, sigma, offset_z, mask,
+                          pix_to_face, kth, vis, wsp, ws_bytes, tuning, stream, true, gt, edt, ref_batch, losses, extras);
 }
 
 int acfm_sil_loss_forward(const float* verts_world, const int64_t* faces, const float* cams, const void* gt,
@@ -2740,7 +2758,7 @@ static int sil_backward_impl(const float* verts_world, const int64_t* faces, con
                              const void* mask, const uint64_t* kth, BwdGrad bg, int N, int V,
                              int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
                              float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
-                             const AcfmRasterTuning* tuning, void* stream) {
+                             const AcfmRasterTuning* tuning, void* stream, const float* gproj = nullptr) {
   if (!verts_world || !faces || !cams || !mask || !kth || !wsp) return ACFM_E_BADARG;
   if (!bg.grad_mask && (!bg.go || bg.lrb <= 0 || N % bg.lrb != 0)) return ACFM_E_BADARG;
   if (bad_dims(N, V, F, H) || !(sigma > 0.f) || blur_radius < 0.f) return ACFM_E_BADARG;
@@ -2771,10 +2789,10 @@ static int sil_backward_impl(const float* verts_world, const int64_t* faces, con
     ProfScope ps(ACFM_PROF_PROJ_BWD, st);
     if (tn.deterministic)
       hipLaunchKernelGGL((k_project_bwd<3>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
-                         reinterpret_cast<float*>(ws.grad_fix), V, grad_verts, grad_cams);
+                         reinterpret_cast<float*>(ws.grad_fix), V, grad_verts, grad_cams, gproj);
     else
       hipLaunchKernelGGL((k_project_bwd<1>), dim3(N), dim3(TPB), 0, st, verts_world, cams,
-                         ws.grad_ndc, V, grad_verts, grad_cams);
+                         ws.grad_ndc, V, grad_verts, grad_cams, gproj);
     ACFM_CHECK_LAUNCH();
   }
   return ACFM_OK;
@@ -2791,6 +2809,34 @@ int acfm_sil_backward(const float* verts_world, const int64_t* faces, const floa
   bg.lrb = 1;
   return sil_backward_impl(verts_world, faces, cams, mask, kth, bg, N, V, F, H, blur_radius, sigma, offset_z,
                            grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream);
+}
+
+int acfm_sil_backward_ex(const float* verts_world, const int64_t* faces, const float* cams,
+                         const void* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                         int F, int H, float blur_radius, float sigma, float offset_z, float* grad_verts,
+                         float* grad_cams, void* wsp, size_t ws_bytes, int ws_from_forward,
+                         const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream) {
+  if (!grad_mask) return ACFM_E_BADARG;
+  BwdGrad bg = {};
+  bg.grad_mask = grad_mask;
+  bg.lrb = 1;
+  return sil_backward_impl(verts_world, faces, cams, mask, kth, bg, N, V, F, H, blur_radius, sigma, offset_z,
+                           grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream,
+                           extras ? extras->grad_proj_xy : nullptr);
+}
+
+int acfm_sil_loss_backward_ex(const float* verts_world, const int64_t* faces, const float* cams, const void* mask,
+                              const uint64_t* kth, const void* gt, const void* edt, int ref_batch,
+                              const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
+                              float offset_z, float* grad_verts, float* grad_cams, void* wsp, size_t ws_bytes,
+                              int ws_from_forward, const AcfmRasterTuning* tuning, const AcfmSilExtras* extras,
+                              void* stream) {
+  if (!grad_losses) return ACFM_E_BADARG;
+  BwdGrad bg = {};
+  bg.lgt = gt; bg.ledt = edt; bg.go = grad_losses; bg.lrb = ref_batch;
+  return sil_backward_impl(verts_world, faces, cams, mask, kth, bg, N, V, F, H, blur_radius, sigma, offset_z,
+                           grad_verts, grad_cams, wsp, ws_bytes, ws_from_forward, tuning, stream,
+                           extras ? extras->grad_proj_xy : nullptr);
 }
 
 int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const float* cams, const void* mask,

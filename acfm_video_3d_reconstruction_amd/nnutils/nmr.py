@@ -40,6 +40,7 @@ class NeuralRenderer(torch.nn.Module):
         self.blur_radius = math.log(1. / 1e-4 - 1.) * sigma  # nmr.py:157
         self.proj_fn = geom_utils.orthographic_proj_withz    # nmr.py:117
         self.offset_z = 0.                                   # nmr.py:119 (monocular: 5.)
+        self._last_proj = None                               # (see project_points)
 
     def ambient_light_only(self):  # nmr.py:121 (no-op in the reference too)
         return
@@ -49,8 +50,20 @@ class NeuralRenderer(torch.nn.Module):
 
     def project_points(self, verts, cams):  # nmr.py:127-129
         if self.proj_fn is geom_utils.orthographic_proj_withz:   # the default: (x, y) straight from the kernel
+            # the trainer projects the prediction it has just rendered (main.py:620 / :715, predictor.py:317 / :319):
+            # the silhouette render's face setup produced exactly these (x, y) -- same function, same bits -- as an
+            # output of its own autograd node, so the boundary loss's gradient returns through that render's ONE
+            # projection backward (no second projection kernel, no sum of two vertex / camera gradients).  Handed out
+            # once, and only for the very tensors of the render (storage, version, shape).
+            hit = self._last_proj
+            if hit is not None and verts.dtype == torch.float32 and hit[0] == ops._proj_key(verts, cams):
+                self._last_proj = None
+                return hit[1]
             return ops.project_xy(verts, cams, 0.)
         return self.proj_fn(verts, cams)[:, :, :2]
+
+    def _remember_proj(self, pix_to_face):
+        self._last_proj = getattr(pix_to_face, "_acfm_proj", None) if self.proj_fn is geom_utils.orthographic_proj_withz else None
 
     def rasterize_of(self, verts, faces, R=None, T=None):
         """nmr.py:131-141: hard K=1 raster of already-projected verts.  The reference passes
@@ -73,6 +86,7 @@ class NeuralRenderer(torch.nn.Module):
                                                 K=self.faces_per_pixel, blur=self.blur_radius,
                                                 sigma=self.sigma, offset_z=self.offset_z,
                                                 k_out=self.pix_to_face_slots, storage=self.storage)
+            self._remember_proj(pix_to_face)
             return masks, pix_to_face
         self.mask_only = False
         if not atlas:  # nmr.py:177-179: Textures(verts_rgb), visualisation only (no gradients)
@@ -95,6 +109,7 @@ class NeuralRenderer(torch.nn.Module):
                                                         K=self.faces_per_pixel, blur=self.blur_radius,
                                                         sigma=self.sigma, offset_z=self.offset_z,
                                                         k_out=self.pix_to_face_slots, storage=self.storage)
+        self._remember_proj(pix_to_face)
         if raw:
             return out, masks, pix_to_face
         return (out[:, 0], out[:, 1] / (out[:, 2] + eps), out[:, 3]), masks, pix_to_face

@@ -895,53 +895,65 @@ class _SilRender(torch.autograd.Function):
                        torch.empty((N, H, H), dtype=torch.float32, device=v.device),
                        torch.empty((N, H, H, 1), dtype=torch.int64, device=v.device),
                        torch.empty((N, H, H), dtype=torch.int32, device=v.device))
+        # NeuralRenderer.project_points of these very vertices and cameras (main.py:715, predictor.py:319: the boundary
+        # loss's input) comes out of the face setup (AcfmSilExtras.proj_xy) and its gradient goes back through THIS
+        # operator's one projection backward: no second projection kernel either way, no sum of two vertex / camera
+        # gradients afterwards (k_project, k_project_bwd and two torch adds less per step)
+        proj = torch.empty((N, V, 2), dtype=torch.float32, device=v.device)
+        exp, _ex_keep = _lib.sil_extras(proj_xy=proj, prefill=prefill)
         with torch.cuda.device(v.device):
-            if prefill is not None:
-                _lib.check(_lib.lib().acfm_sil_forward_prefill(
-                    _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
-                    float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
-                    _lib.ptr(ws), nb, tp, _lib.ptr(prefill[0]), _lib.ptr(prefill[1]), _lib.ptr(prefill[2]),
-                    _lib.ptr(prefill[3]), _lib.cur_stream(v.device)), "acfm_sil_forward_prefill")
-            else:
-                _lib.check(_lib.lib().acfm_sil_forward(
-                    _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
-                    float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
-                    _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)), "acfm_sil_forward")
+            _lib.check(_lib.lib().acfm_sil_forward_ex(
+                _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), N, V, F, H, K, int(k_out), float(blur), float(sigma),
+                float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth), _lib.ptr(vis),
+                _lib.ptr(ws), nb, tp, exp, _lib.cur_stream(v.device)), "acfm_sil_forward_ex")
         _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune, prefill)
         ctx.save_for_backward(v, f, c, mask, kth)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z))
         ctx.ws = (ws, nb, tune)  # face records + tile schedule: reused by backward (no second setup)
         ctx.mark_non_differentiable(p2f, vis)
         ctx.set_materialize_grads(False)  # no zero-filled [N,H,H,K] int64 "gradient" for pix_to_face
-        return mask, p2f, vis
+        return mask, p2f, vis, proj
 
     @staticmethod
-    def backward(ctx, gmask, _gp2f, _gvis):
+    def backward(ctx, gmask, _gp2f, _gvis, gproj):
         v, f, c, mask, kth = ctx.saved_tensors
         H, blur, sigma, offset_z = ctx.cfg
         N, V, _ = v.shape
         F = f.shape[1]
-        if gmask is None:
+        if gmask is None and gproj is None:
             return (None,) * 10
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
+        gp = _f32c(gproj) if gproj is not None else None
+        if gmask is None:        # only the projection was used: its own backward
+            with torch.cuda.device(v.device):
+                _lib.check(_lib.lib().acfm_project_xy_backward(_lib.ptr(v), _lib.ptr(c), _lib.ptr(gp), N, V, _lib.ptr(gv),
+                                                               _lib.ptr(gc), _lib.cur_stream(v.device)),
+                           "acfm_project_xy_backward")
+            return (gv, None, gc) + (None,) * 7
         ws, nb, tune = ctx.ws
+        exp, _ex_keep = _lib.sil_extras(grad_proj_xy=gp)
         pay = gmask.take("mask_losses", mask) if type(gmask) is LazyGrad else None
         if pay is not None:      # the silhouette losses' gradient, still unformed: the backward kernel forms it per pixel
             _m, lg, le, rb, go = pay
             with torch.cuda.device(v.device):
-                _lib.check(_lib.lib().acfm_sil_loss_backward(
+                _lib.check(_lib.lib().acfm_sil_loss_backward_ex(
                     _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(lg), _lib.ptr(le), rb,
                     _lib.ptr(go), N, V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
-                    _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_loss_backward")
+                    _lib.tuning_ptr(tune), exp, _lib.cur_stream(v.device)), "acfm_sil_loss_backward_ex")
             return (gv, None, gc) + (None,) * 7
         g = _f32c(gmask)
         with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().acfm_sil_backward(
+            _lib.check(_lib.lib().acfm_sil_backward_ex(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), N,
                 V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
-                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_backward")
+                _lib.tuning_ptr(tune), exp, _lib.cur_stream(v.device)), "acfm_sil_backward_ex")
         return (gv, None, gc) + (None,) * 7
+
+
+def _proj_key(verts, cams):
+    return (verts.data_ptr(), verts._version, tuple(verts.shape), str(verts.dtype), cams.data_ptr(), cams._version,
+            tuple(cams.shape), str(cams.dtype))
 
 
 def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_SIGMA, offset_z=0.0,
@@ -953,12 +965,16 @@ def sil_render(verts, faces, cams, img_size, K=SIL_K, blur=SIL_BLUR, sigma=SIL_S
     along on the pix_to_face tensor object as `._acfm_vis`."""
     f16 = _is_f16(storage)   # "f16": mask [N,H,H] float16, pix_to_face [N,H,H,1] int32 (BASELINE config 5); fp32 arithmetic
     lazy = k_out == "lazy" and not f16 and K > 1
-    mask, p2f, vis = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z,
-                                      1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)), f16)
+    mask, p2f, vis, proj = _SilRender.apply(verts, faces, cams, img_size, K, blur, sigma, offset_z,
+                                            1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)), f16)
     if lazy:   # k_out="lazy": [N,H,H,K] whose slots 1.. are rendered on first use (LazyPixToFace)
-        return mask, _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
-                                       int(img_size), int(K), blur, sigma, offset_z)
-    p2f._acfm_vis = vis
+        p2f = _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
+                                int(img_size), int(K), blur, sigma, offset_z)
+    else:
+        p2f._acfm_vis = vis
+    # the (x, y) projection of these vertices under these cameras, an output of the render's autograd node: rides on
+    # the pix_to_face object like the visibility bitmap (NeuralRenderer.project_points picks it up)
+    p2f._acfm_proj = (_proj_key(verts, cams), proj)
     return mask, p2f
 
 
@@ -992,38 +1008,48 @@ class _SilRenderLosses(torch.autograd.Function):
         if f16:
             tune = _lib.with_f16(tune, True)
         tp = _lib.tuning_ptr(tune)
+        proj = torch.empty((N, V, 2), dtype=torch.float32, device=v.device)      # (see _SilRender.forward)
+        exp, _ex_keep = _lib.sil_extras(proj_xy=proj)
         with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().acfm_sil_loss_forward(
+            _lib.check(_lib.lib().acfm_sil_loss_forward_ex(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(g), _lib.ptr(e), RB, N, V, F, H, K, int(k_out),
                 float(blur), float(sigma), float(offset_z), _lib.ptr(mask), _lib.ptr(p2f), _lib.ptr(kth),
-                _lib.ptr(vis), _lib.ptr(losses), _lib.ptr(ws), nb, tp, _lib.cur_stream(v.device)),
-                "acfm_sil_loss_forward")
+                _lib.ptr(vis), _lib.ptr(losses), _lib.ptr(ws), nb, tp, exp, _lib.cur_stream(v.device)),
+                "acfm_sil_loss_forward_ex")
         _remember_setup(v, c, f, H, offset_z, ws, nb, blur, tune)
         ctx.save_for_backward(v, f, c, mask, kth, g, e)
         ctx.cfg = (H, float(blur), float(sigma), float(offset_z), RB)
         ctx.ws = (ws, nb, tune)
         ctx.mark_non_differentiable(mask, p2f, vis)
         ctx.set_materialize_grads(False)
-        return losses, mask, p2f, vis
+        return losses, mask, p2f, vis, proj
 
     @staticmethod
-    def backward(ctx, glosses, _gm, _gp, _gv):
+    def backward(ctx, glosses, _gm, _gp, _gv, gproj):
         v, f, c, mask, kth, g, e = ctx.saved_tensors
         H, blur, sigma, offset_z, RB = ctx.cfg
         N, V, _ = v.shape
         F = f.shape[1]
         none = (None,) * 12
-        if glosses is None:
+        if glosses is None and gproj is None:
             return none
-        go = _f32c(glosses)
         gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
+        gp = _f32c(gproj) if gproj is not None else None
+        if glosses is None:      # only the projection was used: its own backward
+            with torch.cuda.device(v.device):
+                _lib.check(_lib.lib().acfm_project_xy_backward(_lib.ptr(v), _lib.ptr(c), _lib.ptr(gp), N, V, _lib.ptr(gv),
+                                                               _lib.ptr(gc), _lib.cur_stream(v.device)),
+                           "acfm_project_xy_backward")
+            return (gv, None, gc) + none[3:]
+        go = _f32c(glosses)
         ws, nb, tune = ctx.ws
+        exp, _ex_keep = _lib.sil_extras(grad_proj_xy=gp)
         with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().acfm_sil_loss_backward(
+            _lib.check(_lib.lib().acfm_sil_loss_backward_ex(
                 _lib.ptr(v), _lib.ptr(f), _lib.ptr(c), _lib.ptr(mask), _lib.ptr(kth), _lib.ptr(g), _lib.ptr(e), RB,
                 _lib.ptr(go), N, V, F, H, blur, sigma, offset_z, _lib.ptr(gv), _lib.ptr(gc), _lib.ptr(ws), nb, 1,
-                _lib.tuning_ptr(tune), _lib.cur_stream(v.device)), "acfm_sil_loss_backward")
+                _lib.tuning_ptr(tune), exp, _lib.cur_stream(v.device)), "acfm_sil_loss_backward_ex")
         return (gv, None, gc) + none[3:]
 
 
@@ -1036,13 +1062,15 @@ def sil_render_losses(verts, faces, cams, img_size, gt=None, edt=None, K=SIL_K, 
     [N/G,...] shared by the G hypotheses of a frame."""
     f16 = _is_f16(storage)   # "f16": mask and the references are held in float16, the loss sums stay float32
     lazy = k_out == "lazy" and not f16 and K > 1
-    losses, mask, p2f, vis = _SilRenderLosses.apply(verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z,
-                                                    1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)),
-                                                    f16)
+    losses, mask, p2f, vis, proj = _SilRenderLosses.apply(verts, faces, cams, gt, edt, img_size, K, blur, sigma, offset_z,
+                                                          1 if (f16 or lazy) else (K if k_out in (None, "lazy") else int(k_out)),
+                                                          f16)
     if lazy:
-        return losses, mask, _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
-                                               int(img_size), int(K), blur, sigma, offset_z)
-    p2f._acfm_vis = vis
+        p2f = _lazy_pix_to_face(p2f, vis, _f32c(verts), expand_faces(faces, verts.shape[0]), _f32c(cams),
+                                int(img_size), int(K), blur, sigma, offset_z)
+    else:
+        p2f._acfm_vis = vis
+    p2f._acfm_proj = (_proj_key(verts, cams), proj)
     return losses, mask, p2f
 
 

@@ -273,7 +273,7 @@ def roofline_of(kern, alg, workload_key):
         if dom == "k_raster_fwd<K,soft>" and traffic and traffic > 2 * ab:
             roof["traffic_note"] = ("of the bytes moved, ~100 MB are the CONSTANT outputs of the texture render that follows (imgs / sil / "
                                     "texel ids / face ids of the ~85 % empty blocks), stored by this kernel behind its walk "
-                                    "(acfm_sil_forward_prefill) instead of by k_tex_cover: writes moved between kernels, not re-reads")
+                                    "(acfm_sil_forward_ex, AcfmSilExtras.tex_*) instead of by k_tex_cover: writes moved between kernels, not re-reads")
     if traffic:   # what the kernel actually moves: context, not `achieved`
         moved = traffic / (kern[dom]["avg_us"] * 1e-6) / 1e9
         roof.update(moved_gbs=round(moved, 1), moved_frac=round(moved / HBM_PEAK_GBS, 4))

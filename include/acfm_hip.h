@@ -266,18 +266,36 @@ int acfm_sil_forward(const float* verts_world, const int64_t* faces, const float
                      uint64_t* kth, uint8_t* vis, void* ws, size_t ws_bytes, const AcfmRasterTuning* tuning,
                      void* stream);
 
-/* acfm_sil_forward for a silhouette render that a texture render of the same prediction follows (the reference's
- * pair renderer(...) / tex_renderer(...), multiframe/main.py:620-626): besides its own outputs it stores the CONSTANT
- * outputs of that texture render -- imgs 0, sil 0, pix_to_face -1, texel_idx -1 -- on the 8x8 blocks no face comes
- * near (~80 % of a frame), into the caller's buffers for them; acfm_tex_forward(ws_ready = 3) on the same workspace then
- * writes only the blocks with work.  Needs ACFM_RECORD_COVER in the tuning and float storage.  Same results as the
- * plain pair; the constant stores drain behind the K-nearest walk instead of being 2/3 of the texture kernel. */
-int acfm_sil_forward_prefill(const float* verts_world, const int64_t* faces, const float* cams, int N,
-                             int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
-                             float offset_z, void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* ws,
-                             size_t ws_bytes, const AcfmRasterTuning* tuning, float* tex_imgs /* [N,3,H,H] */,
-                             float* tex_sil /* [N,H,H] */, int64_t* tex_pix_to_face /* [N,H,H,1] */,
-                             int32_t* tex_texel_idx /* [N,H,H] */, void* stream);
+/* Extras of the silhouette render for what the reference's callers do NEXT TO it with the same vertices and cameras
+ * (every field optional, NULL = not wanted; the `_ex` entry points are their plain namesakes + this structure):
+ *   proj_xy         forward out [N,V,2]: NeuralRenderer.project_points(vertices, cams) (nmr.py:127-129), which the
+ *                   trainer calls on the prediction it has just rendered (main.py:715, predictor.py:319): the face
+ *                   setup projects the vertices anyway, so it hands (x, y) out instead of a second projection kernel;
+ *   grad_proj_xy    backward in [N,V,2]: the upstream gradient of that proj_xy (the boundary loss's), added inside the
+ *                   ONE projection backward of the silhouette render -- no second projection backward, no sum of two
+ *                   [N,V,3] / [N,7] gradients afterwards;
+ *   tex_*           forward: the pair renderer(...) / tex_renderer(...) on one prediction (main.py:620-626): besides its
+ *                   own outputs the silhouette kernel stores the CONSTANT outputs of that texture render -- imgs 0, sil 0,
+ *                   pix_to_face -1, texel_idx -1 -- on the 8x8 blocks no face comes near (~80 % of a frame) into the
+ *                   caller's buffers for them (all four or none; needs ACFM_RECORD_COVER and float storage);
+ *                   acfm_tex_forward(ws_ready = 3) on the same workspace then writes only the blocks with work. */
+typedef struct AcfmSilExtras {
+  float* proj_xy;
+  const float* grad_proj_xy;
+  float* tex_imgs;            /* [N,3,H,H] */
+  float* tex_sil;             /* [N,H,H] */
+  int64_t* tex_pix_to_face;   /* [N,H,H,1] */
+  int32_t* tex_texel_idx;     /* [N,H,H] */
+} AcfmSilExtras;
+int acfm_sil_forward_ex(const float* verts_world, const int64_t* faces, const float* cams, int N,
+                        int V, int F, int H, int K, int k_out, float blur_radius, float sigma,
+                        float offset_z, void* mask, void* pix_to_face, uint64_t* kth, uint8_t* vis, void* ws,
+                        size_t ws_bytes, const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream);
+int acfm_sil_backward_ex(const float* verts_world, const int64_t* faces, const float* cams,
+                         const void* mask, const uint64_t* kth, const float* grad_mask, int N, int V,
+                         int F, int H, float blur_radius, float sigma, float offset_z,
+                         float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
+                         int ws_from_forward, const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream);
 
 /* replaces autograd through SoftSilhouetteShader + pytorch3d._C.rasterize_meshes_backward
  * (dists path) + the projection chain.  mask / kth are the forward's outputs;
@@ -310,6 +328,17 @@ int acfm_sil_loss_backward(const float* verts_world, const int64_t* faces, const
                            const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
                            float offset_z, float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
                            int ws_from_forward, const AcfmRasterTuning* tuning, void* stream);
+int acfm_sil_loss_forward_ex(const float* verts_world, const int64_t* faces, const float* cams, const void* gt /* [real] */,
+                             const void* edt /* [real] */, int ref_batch, int N, int V, int F, int H, int K, int k_out,
+                             float blur_radius, float sigma, float offset_z, void* mask, void* pix_to_face,
+                             uint64_t* kth, uint8_t* vis, float* losses, void* ws, size_t ws_bytes,
+                             const AcfmRasterTuning* tuning, const AcfmSilExtras* extras, void* stream);
+int acfm_sil_loss_backward_ex(const float* verts_world, const int64_t* faces, const float* cams, const void* mask,
+                              const uint64_t* kth, const void* gt, const void* edt, int ref_batch,
+                              const float* grad_losses, int N, int V, int F, int H, float blur_radius, float sigma,
+                              float offset_z, float* grad_verts, float* grad_cams, void* ws, size_t ws_bytes,
+                              int ws_from_forward, const AcfmRasterTuning* tuning, const AcfmSilExtras* extras,
+                              void* stream);
 
 /* ---- hard rasteriser (K = 1, blur 0) -------------------------------------------------
  * replaces OF_NeuralRenderer.forward (multiframe/nnutils/nmr.py:224-238): verts are
@@ -332,7 +361,7 @@ int acfm_hard_raster(const float* verts_proj, const int64_t* faces, int N, int V
  * face setup are skipped and the blur-expanded boxes tightened by sqrt(ws_blur).
  * ws_ready == 2: that acfm_sil_forward ran with ACFM_RECORD_COVER (and the same tuning is passed here): the nearest
  * covering face of every pixel is read from the workspace, nothing is binned or walked.
- * ws_ready == 3: as 2, and that render was acfm_sil_forward_prefill with THESE imgs / sil / pix_to_face / texel_idx
+ * ws_ready == 3: as 2, and that render was acfm_sil_forward_ex (AcfmSilExtras.tex_*) with THESE imgs / sil / pix_to_face / texel_idx
  * buffers: the blocks no face comes near hold their constants already and are not written again.
  * atlas_batch: number of distinct atlases, atlas [atlas_batch,F,R,R,3]; mesh n samples atlas
  * n % atlas_batch (the trainer renders G camera hypotheses of every frame with the frame's one

@@ -284,3 +284,70 @@ def test_headline_step_vs_the_cpu_full_step(meshes):
                             (g_atlas, ref["g_atlas"], "atlas")):
         got = got.cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg=what)
+
+
+def test_project_points_comes_out_of_the_render(meshes):
+    """NeuralRenderer.project_points(verts, cams) right after forward(verts, faces, cams) (main.py:620 / :715,
+    predictor.py:317 / :319) is an output of the render's own node (AcfmSilExtras.proj_xy: the face setup projects the
+    vertices anyway): bit-identical to the stand-alone projection; the boundary loss's gradient returns through the
+    render's one projection backward and equals the two-operator path; it is handed out once and only for the very
+    tensors of the render; other vertices / cameras, a modified tensor, or no render before fall back to the kernel."""
+    from acfm_video_3d_reconstruction_amd import _lib, ops
+    from acfm_video_3d_reconstruction_amd.nnutils import loss_utils as L
+    from acfm_video_3d_reconstruction_amd.nnutils.nmr import NeuralRenderer
+    d = _d()
+    N, H = 4, 64
+    I = _inputs(meshes, "horse", N, H, 2, 41, d)
+    ren = NeuralRenderer(H)
+
+    def run(shared, fused=False):
+        tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+        tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+        if fused:
+            (l1, _, e), mask, p2f = ren.forward_silhouette_losses(tv, I["faces"], tc, I["gt"], I["edt"])
+            sil = (l1 + 0.1 * e).mean()
+        else:
+            mask, p2f = ren(tv, I["faces"], tc)
+            sil = L.l1_loss(mask, I["gt"]) + 0.1 * L.edt_loss(mask, I["edt"])
+        proj = ren.project_points(tv, tc) if shared else ops.project_xy(tv, tc)
+        b = L.bds_loss(proj, I["bds"], I["faces"], p2f)
+        (sil + 0.3 * b).backward()
+        return proj.detach(), tv.grad, tc.grad
+    lib = _lib.lib()
+    for fused in (False, True):
+        lib.acfm_prof_enable(1)
+        try:
+            p1, gv1, gc1 = run(True, fused)
+            torch.cuda.synchronize()
+            ran = _lib.prof_collect()
+        finally:
+            lib.acfm_prof_enable(0)
+        assert "k_project" not in ran and ran["k_project_bwd"][1] == 1, ran      # one projection backward, no projection kernel
+        p0, gv0, gc0 = run(False, fused)
+        assert torch.equal(p1, p0)
+        assert float((gv1 - gv0).abs().max()) <= 2e-6 * float(gv0.abs().max())
+        assert float((gc1 - gc0).abs().max()) <= 2e-6 * float(gc0.abs().max())
+    # only the projection used (no loss on the mask): its own backward
+    tv = torch.tensor(I["verts"], device=d, requires_grad=True)
+    tc = torch.tensor(I["cams"], device=d, requires_grad=True)
+    ren(tv, I["faces"], tc)
+    w = torch.randn(N, I["verts"].shape[1], 2, device=d)
+    (ren.project_points(tv, tc) * w).sum().backward()
+    tv2 = torch.tensor(I["verts"], device=d, requires_grad=True)
+    tc2 = torch.tensor(I["cams"], device=d, requires_grad=True)
+    (ops.project_xy(tv2, tc2) * w).sum().backward()
+    assert torch.allclose(tv.grad, tv2.grad, rtol=1e-6, atol=1e-8) and torch.allclose(tc.grad, tc2.grad, rtol=1e-5, atol=1e-6)
+    # handed out once; other tensors, a modified tensor, no render before: the stand-alone kernel, same values
+    ren(tv, I["faces"], tc)
+    a = ren.project_points(tv, tc)
+    b2 = ren.project_points(tv, tc)
+    assert a.grad_fn is not b2.grad_fn and torch.equal(a, b2)
+    ren(tv, I["faces"], tc)
+    other = (tv.detach() * 1.01).requires_grad_(True)
+    assert torch.equal(ren.project_points(other, tc), ops.project_xy(other, tc))
+    assert ren.project_points(tv, tc).grad_fn is not None       # (the cached one is still there for the right tensors)
+    ren(tv, I["faces"], tc)
+    with torch.no_grad():
+        tv.mul_(1.5)
+    assert torch.equal(ren.project_points(tv, tc), ops.project_xy(tv, tc))      # version moved: recomputed for the new values
+    assert torch.equal(NeuralRenderer(H).project_points(tv, tc), ops.project_xy(tv, tc))
