@@ -145,6 +145,17 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   const float INF = __builtin_inff();
   float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
   bool big = false;
+  auto count_box = [&](int xa, int ya, int xb, int yb) {   // pixel range (clamped to the image) -> +1 on its 8x8 blocks
+    xa /= CNT_TILE; ya /= CNT_TILE; xb /= CNT_TILE; yb /= CNT_TILE;
+    if ((xb - xa + 1) * (yb - ya + 1) > 256) {
+      big = true;  // too many tiles to count one by one: every tile of the mesh gets +1 below
+    } else
+      for (int ty = ya; ty <= yb; ++ty)
+        for (int tx = xa; tx <= xb; ++tx) {
+          if (lds_cnt) atomicAdd(&s_cnt[ty * tiles_ + tx], 1);
+          else atomicAdd(&ws.tile_cnt[((size_t)n * tiles_ + ty) * tiles_ + tx], 1);
+        }
+  };
   for (int f = f_lo + tid; f < f_hi; f += TPB) {
     const int64_t* fi = faces + ((size_t)n * F + f) * 3;
     int i0 = (int)fi[0], i1 = (int)fi[1], i2 = (int)fi[2];
@@ -198,16 +209,33 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
             if (lds_mask) atomicOr(&s_mask[row * w_n + ((f >> 5) - w_lo)], bit);
             else atomicOr(&g_mask[(size_t)row * mwords + (f >> 5)], bit);
           }
-        // cost estimate for heavy-first scheduling: +1 on every 16x16 tile the box may touch
-        xa /= CNT_TILE; ya /= CNT_TILE; xb /= CNT_TILE; yb /= CNT_TILE;
-        if ((xb - xa + 1) * (yb - ya + 1) > 256) {
-          big = true;  // too many tiles to count one by one: every tile of the mesh gets +1 below
-        } else
-          for (int ty = ya; ty <= yb; ++ty)
-            for (int tx = xa; tx <= xb; ++tx) {
-              if (lds_cnt) atomicAdd(&s_cnt[ty * tiles_ + tx], 1);
-              else atomicAdd(&ws.tile_cnt[((size_t)n * tiles_ + ty) * tiles_ + tx], 1);
-            }
+        // cost estimate for heavy-first scheduling: +1 on every 8x8 block the box may touch.  With the counters in LDS
+        // (images up to 512^2) slice 0 counts ALL faces of the mesh (below) and stores the result: no zero fill of
+        // ws.tile_cnt, no global atomics; larger images: every slice adds its faces to the zeroed array
+        if (!lds_cnt || slice == 0) count_box(xa, ya, xb, yb);
+      }
+    }
+  }
+  if (lds_cnt && slice == 0) {
+    // the faces of the other three slices: box and pixel range again (k_setup's own expressions), counters only
+    for (int f = f_hi + tid; f < F; f += TPB) {
+      const int64_t* fi = faces + ((size_t)n * F + f) * 3;
+      int i0 = (int)fi[0], i1 = (int)fi[1], i2 = (int)fi[2];
+      i0 = min(max(i0, 0), V - 1); i1 = min(max(i1, 0), V - 1); i2 = min(max(i2, 0), V - 1);
+      const float x0 = s_v[3 * i0], y0 = s_v[3 * i0 + 1], x1 = s_v[3 * i1], y1 = s_v[3 * i1 + 1];
+      const float x2 = s_v[3 * i2], y2 = s_v[3 * i2 + 1];
+      const float area = edge_fn(x2, y2, x0, y0, x1, y1);
+      if (area <= ACFM_K_EPS && area >= -1.0f * ACFM_K_EPS) continue;
+      const float b_x = min3f(x0, x1, x2) - margin, b_y = max3f(x0, x1, x2) + margin;
+      const float b_z = min3f(y0, y1, y2) - margin, b_w = max3f(y0, y1, y2) + margin;
+      const float hf = (float)H;
+      int xa = (int)floorf(hf - 1.0f - ((b_y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+      int xb = (int)ceilf(hf - 1.0f - ((b_x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+      int ya = (int)floorf(hf - 1.0f - ((b_w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
+      int yb = (int)ceilf(hf - 1.0f - ((b_z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
+      if (xb >= 0 && yb >= 0 && xa < H && ya < H) {
+        xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
+        count_box(xa, ya, xb, yb);
       }
     }
   }
@@ -215,9 +243,12 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   const int w = tid >> 6;
   if ((tid & 63) == 0) { s_red[w][0] = bx0; s_red[w][1] = bx1; s_red[w][2] = by0; s_red[w][3] = by1; }
   const int any_big = __syncthreads_or(big) ? 1 : 0;  // (also the barrier before the copies below)
-  for (int i = tid; i < tt_; i += TPB) {              // ws.tile_cnt was zeroed by the host
-    const int c = (lds_cnt ? s_cnt[i] : 0) + any_big;
-    if (c != 0) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], c);
+  if (lds_cnt) {
+    if (slice == 0)
+      for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i] + any_big;   // all faces: plain stores
+  } else {
+    for (int i = tid; i < tt_; i += TPB)                // ws.tile_cnt was zeroed by the host
+      if (any_big) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], any_big);
   }
   if (lds_mask)
     for (int i = tid; i < rows * w_n; i += TPB)
@@ -303,6 +334,8 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
 #pragma unroll
   for (int c = 0; c < NCLASS; ++c) cnt[c] = 0;
   int m1 = m_first, bl1 = bl_first;
+  int cst0[OCH];          // the costs of the first OCH entries of this thread: all of them up to 8192 entries per group
+                          // (64 frames @256^2), so that the scatter pass below does not load them again
   for (int it0 = 0; it0 < iters; it0 += OCH) {
     int cst[OCH];
 #pragma unroll
@@ -311,6 +344,7 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
       cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
       bl1 += blockDim.x;
       while (bl1 >= tt) { bl1 -= tt; ++m1; }
+      if (it0 == 0) cst0[u] = cst[u];
     }
 #pragma unroll
     for (int u = 0; u < OCH; ++u) {
@@ -371,7 +405,8 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
 #pragma unroll
     for (int u = 0; u < OCH; ++u) {
       const int e = (it0 + u) * blockDim.x + threadIdx.x;
-      cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
+      if (it0 == 0) cst[u] = cst0[u];
+      else cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
       bl1 += blockDim.x;
       while (bl1 >= tt) { bl1 -= tt; ++m1; }
     }
@@ -2298,7 +2333,13 @@ constexpr int TEXG_MAX_R = 8;
 #define ACFM_TEXG_FPW 4
 #endif
 constexpr int TEXG_FPW = ACFM_TEXG_FPW;      // faces per wave: their boxes, texel indices and gradients are loaded side by side
-constexpr int TEXG_U = 8;        // big boxes: 64 U pixels per round, all their loads in flight together
+#ifndef ACFM_TEXG_U
+#define ACFM_TEXG_U 2    // (with 8 waves per SIMD below: 39.8 us per launch; U = 4 at 6 waves 41.4; U = 8 at 5 waves -- 92 VGPRs -- 45.2)
+#endif
+#ifndef ACFM_TEXG_WAVES
+#define ACFM_TEXG_WAVES 8
+#endif
+constexpr int TEXG_U = ACFM_TEXG_U;        // big boxes: 64 U pixels per round, all their loads in flight together
 // Upstream gradient of the rendered image: given ([N,3,H,H]) or, for the fused texture render + masked MSE, formed
 // on the fly from the rendered image, the reference image and mask and the per-mesh gradient of the loss --
 // k_tex_mse_bwd's expression: w (tex m - img m) m with w = go[n] 2 / (3 HW).
@@ -2336,7 +2377,7 @@ __device__ __forceinline__ TexGradN tex_grad_of(const TexGrad& tg, int n, size_t
   t.w = tg.go[n] * 2.0f / (3.0f * (float)HW);
   return t;
 }
-__global__ __launch_bounds__(256) void k_tex_bwd_faces(RasterWs ws, TexGrad tgrad,
+__global__ __launch_bounds__(256, ACFM_TEXG_WAVES) void k_tex_bwd_faces(RasterWs ws, TexGrad tgrad,
                                                        const int32_t* __restrict__ tidx, int N, int F, int H,
                                                        int R, int NA, float box_shrink,
                                                        float* __restrict__ grad_atlas) {
@@ -2499,7 +2540,8 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
                      (lds_mask ? slice_mask_bytes : 0);
   if (lds > 150 * 1024) return ACFM_E_BADARG;
   if (!lds_mask && zero_async(ws.cmask, sizeof(unsigned) * (size_t)N * ctiles * ctiles * mwords, st)) return ACFM_E_LAUNCH;
-  if (zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
+  // (counters in LDS: slice 0 of k_setup stores the counts of all faces, nothing to zero)
+  if (tt > SETUP_LDS_TILES && zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
                      margin, ws, vis, proj_xy);

@@ -7,11 +7,15 @@ NeuralRenderer.project_points (:127-129)    ops.project
 OF_NeuralRenderer.forward (:224-238)        ops.hard_raster
 """
 import math
+import weakref
 
 import torch
 
 from .. import ops
 from . import geom_utils
+
+
+_LAST_PROJ = weakref.WeakKeyDictionary()   # renderer -> (key, projection of its last silhouette render): see project_points
 
 
 class NeuralRenderer(torch.nn.Module):
@@ -40,7 +44,6 @@ class NeuralRenderer(torch.nn.Module):
         self.blur_radius = math.log(1. / 1e-4 - 1.) * sigma  # nmr.py:157
         self.proj_fn = geom_utils.orthographic_proj_withz    # nmr.py:117
         self.offset_z = 0.                                   # nmr.py:119 (monocular: 5.)
-        self._last_proj = None                               # (see project_points)
 
     def ambient_light_only(self):  # nmr.py:121 (no-op in the reference too)
         return
@@ -55,15 +58,21 @@ class NeuralRenderer(torch.nn.Module):
             # output of its own autograd node, so the boundary loss's gradient returns through that render's ONE
             # projection backward (no second projection kernel, no sum of two vertex / camera gradients).  Handed out
             # once, and only for the very tensors of the render (storage, version, shape).
-            hit = self._last_proj
+            hit = _LAST_PROJ.get(self)
             if hit is not None and verts.dtype == torch.float32 and hit[0] == ops._proj_key(verts, cams):
-                self._last_proj = None
+                del _LAST_PROJ[self]
                 return hit[1]
             return ops.project_xy(verts, cams, 0.)
         return self.proj_fn(verts, cams)[:, :, :2]
 
     def _remember_proj(self, pix_to_face):
-        self._last_proj = getattr(pix_to_face, "_acfm_proj", None) if self.proj_fn is geom_utils.orthographic_proj_withz else None
+        # (kept beside the module, not in it: the projection is a non-leaf tensor, which copy.deepcopy / pickling of
+        # the module must never meet)
+        proj = getattr(pix_to_face, "_acfm_proj", None) if self.proj_fn is geom_utils.orthographic_proj_withz else None
+        if proj is not None:
+            _LAST_PROJ[self] = proj
+        else:
+            _LAST_PROJ.pop(self, None)
 
     def rasterize_of(self, verts, faces, R=None, T=None):
         """nmr.py:131-141: hard K=1 raster of already-projected verts.  The reference passes
