@@ -1687,15 +1687,19 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? ACFM_K1_WAVES : 4) void k
                                                     float sigma, FwdOut out) {
   __shared__ __attribute__((aligned(16))) FwdLdsK<K> S;
   const Sched sc = make_sched(ws, N, H, K > 1);   // the K-nearest kernels split their heaviest blocks
-  struct Stamp {
-    unsigned long long* p; unsigned long long t0;
-    __device__ Stamp(unsigned long long* q) : p(q), t0(q ? __builtin_amdgcn_s_memrealtime() : 0) {}
+  struct Stamp {   // diagnostic build: (t_start, t_end, hw | xcc << 32 | (sub + 1) << 36 | cost << 40, t_work_start, t_work_end) per workgroup
+    unsigned long long* p; unsigned long long t0, tw, tf; int sub, cost;
+    __device__ Stamp(unsigned long long* q) : p(q), t0(q ? __builtin_amdgcn_s_memrealtime() : 0), tw(0), tf(0), sub(-1), cost(0) {}
+    __device__ void work(int sub_, int cost_) { if (p) { tw = __builtin_amdgcn_s_memrealtime(); sub = sub_; cost = cost_; } }
+    __device__ void work_end() { if (p) tf = __builtin_amdgcn_s_memrealtime(); }
     __device__ ~Stamp() {
       if (p && threadIdx.x == 0) {
         unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
-        p[3 * (size_t)blockIdx.x] = t0; p[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        p[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+        p[5 * (size_t)blockIdx.x] = t0; p[5 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p[5 * (size_t)blockIdx.x + 2] = ((unsigned long long)(cost & 0xffff) << 40) | ((unsigned long long)(sub + 1) << 36) |
+                                        ((unsigned long long)xcc << 32) | hw;
+        p[5 * (size_t)blockIdx.x + 3] = tw; p[5 * (size_t)blockIdx.x + 4] = tf;
       }
     }
   } stamp(out.dbg);
@@ -1734,9 +1738,20 @@ __global__ __launch_bounds__(RT, K > 20 ? 2 : K == 1 ? ACFM_K1_WAVES : 4) void k
 #ifdef ACFM_DIAG_NO_WORK
     if (K == 1) continue;
 #endif
-    if (!t.none) fwd_block<K, CLIP, TEX>(ws, t, F, H, blur, sigma, out, S);
+    if (!t.none) {
+#ifdef ACFM_DIAG
+      if (out.dbg) {
+        const int tiles_ = (H + RBLK - 1) / RBLK;
+        stamp.work(t.sub, block_cost(ws, t.n, __builtin_amdgcn_readfirstlane((t.yi / RBLK) * tiles_ + t.xi / RBLK), H));
+      }
+#endif
+      fwd_block<K, CLIP, TEX>(ws, t, F, H, blur, sigma, out, S);
+    }
     wave_lds_sync();   // the next block reuses the LDS lists
   }
+#ifdef ACFM_DIAG
+  stamp.work_end();
+#endif
 }
 
 // Texture forward from the cover plane (ACFM_RECORD_COVER, acfm_tex_forward ws_ready = 2): the K-nearest render of this
