@@ -39,7 +39,7 @@ python3 bench.py --config 4 > $o/${tag}_bench_config4.json 2> $o/bench4.err || {
 # scaling measurement -- both ranks share the card -- but every line of the --gpus N path runs
 for c in 2 4; do
   ACFM_DIST_BACKEND=gloo ACFM_ALL_RANKS_ON_GPU0=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-    --master-port 2951$c bench.py --gpus 2 --config $c --steps 10 --warmup 3 --no-cpu --headline-only > $o/${tag}_world2_rehearsal_config$c.json 2> $o/world2_$c.err || { tail -5 $o/world2_$c.err; exit 1; }
+    --master-port 2951$c bench.py --gpus 2 --config $c --steps 10 --warmup 3 --no-cpu --headline-only 2> $o/world2_$c.err | grep "^{" > $o/${tag}_world2_rehearsal_config$c.json || { tail -5 $o/world2_$c.err; exit 1; }
 done
 # 4. the callers either side of the render path
 (python3 tools/step_bench.py; python3 tools/step_bench.py --graph; python3 tools/solve_bench.py; python3 tools/refine_bench.py) > $o/${tag}_step_solve_refine.txt 2>&1
