@@ -439,9 +439,10 @@ def run_config2_or_5(ctx):
             flat_extra.copy_(total.detach().reshape(1))
         return total.detach(), g_delta, g_cams, g_mean, g_atlas
 
-    def exchange(outs):
+    def exchange(outs, collective=True):
         if world > 1:  # the one exchange: shared mean-shape gradient + loss scalar
-            reducer.reduce_packed()
+            if collective:
+                reducer.reduce_packed()
             mean_p.grad = flat_views[0]
         else:
             mean_p.grad = outs[3]
@@ -464,8 +465,9 @@ def run_config2_or_5(ctx):
 
     unpack_graph = []
 
-    def exchange_shape(outs, graph_ok=True):
-        ex.reduce()      # ONE all-reduce (RCCL) of ~49 KB
+    def exchange_shape(outs, graph_ok=True, collective=True):
+        if collective:
+            ex.reduce()      # ONE all-reduce (RCCL) of ~49 KB
         # d lbs = solve_backward(G) on every rank (acfm_deform_solve_backward) + the mean-shape gradient: a second small
         # hipGraph behind the collective when the step is replayed (the three launches + two copies are ~0.1 ms of host
         # time when issued from Python)
@@ -474,9 +476,9 @@ def run_config2_or_5(ctx):
         else:
             ex.unpack()
 
-    def make_step(shape_mode, ren=renderer, fused=False, use_graph=True):
+    def make_step(shape_mode, ren=renderer, fused=False, use_graph=True, collective=True):
         comp = (lambda: compute_shape(ren, fused)) if shape_mode else (lambda: compute(ren, fused))
-        exch = exchange_shape if shape_mode else exchange
+        exch = (lambda o: exchange_shape(o, collective=collective)) if shape_mode else (lambda o: exchange(o, collective=collective))
         if use_graph:
             # The step's ~60 launches (forward, backward, every gradient buffer, the pack of the exchange buffer) captured
             # once into a hipGraph and replayed: shapes are static, every entry point of libacfm_hip.so is stream-ordered,
@@ -499,7 +501,7 @@ def run_config2_or_5(ctx):
         def eager():
             outs = comp()
             if shape_mode:
-                exchange_shape(outs, graph_ok=False)
+                exchange_shape(outs, graph_ok=False, collective=collective)
             else:
                 exch(outs)
             return outs
@@ -515,6 +517,17 @@ def run_config2_or_5(ctx):
     half_w = max(2, a.warmup // 2)
     extras = not cfg5 and not a.headline_only and side is None
     legs = {}
+    if world > 1:
+        # the SAME step on every rank at once with the collective left out: what one GPU of this job does per step when it
+        # waits for nobody -- the like-for-like base of a weak-scaling ratio, measured in this very run (with --shared shape
+        # the --gpus 1 line's `value` is a lighter step: fixed handle weights, no per-step factorisation)
+        fn, g_ok = make_step(headline_shape, use_graph=use_graph, collective=False)
+        dt_local = ctx.time_steps(fn, half_w, a.steps)
+        legs["same_step_no_exchange"] = {
+            "value_per_gpu": round(N * a.steps / dt_local, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_local / a.steps, 4),
+            "note": "every rank runs the headline step of this line without the all-reduce (max over ranks): "
+                    "n_gpus x value_per_gpu is what perfect weak scaling of THIS step would give"}
+        ops.invalidate_setups()
     if extras:
         # the other launch mode of the same step, reported beside the headline (never instead of it)
         fn, _ = make_step(headline_shape, use_graph=not graphed)
@@ -528,7 +541,10 @@ def run_config2_or_5(ctx):
                   "[G = sum g delta^T | sum g | loss] (%d bytes); what --gpus N > 1 times per GPU" % ex.bytes) if not headline_shape
             else "fixed handle weights, the mean-shape gradient alone is exchanged (7.7 KB): the --gpus 1 headline step per GPU",
             launch="one hipGraph replay per step" if g_ok else "eager")
-    if not a.no_lean and not cfg5 and side is None:
+    # (from here on: single-process legs.  A multi-rank run times the headline, its no-exchange twin, the other launch mode
+    # and the other choice of shared parameters -- every leg a collective of all ranks -- and nothing else)
+    solo = world == 1
+    if solo and not a.no_lean and not cfg5 and side is None:
         # same step with every slot of pix_to_face [N,H,W,20] stored at render time (160 bytes per pixel nobody in the
         # step reads) instead of the default's nearest-face plane + the other planes on first use; beside the headline
         lean = NeuralRenderer(H, pix_to_face_slots=20)
@@ -538,7 +554,7 @@ def run_config2_or_5(ctx):
             note="NeuralRenderer(pix_to_face_slots=20): all 20 planes of pix_to_face written by the render "
                  "(the default returns the same [N,H,W,20] int64 tensor lazily: nearest-face plane written, "
                  "the other planes rendered when first touched -- never, in this step)")
-    if extras:
+    if extras and solo:
         # same step through the opt-in fused render+loss operator (the silhouette losses leave the raster kernel with
         # the mask; no separate passes over the mask, no [N,H,W] mask gradient); beside the headline, never instead of it
         fn, _ = make_step(headline_shape, fused=True, use_graph=use_graph)
@@ -558,10 +574,13 @@ def run_config2_or_5(ctx):
     # Boundaries_Loss wrapped in nn.DataParallel (:183-193, :326), mirror_sample's flip of mask_pred (:98), l1_loss and
     # edt_loss as separate reduce=False operators (:644, :716), the texture MSE written in torch ops (:655-662), the
     # default (lazy) pix_to_face through DataParallel's scatter.  Beside the headline, never instead of it.
-    if extras and a.tex:
-        dp_renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()
-        dp_tex_renderer = torch.nn.DataParallel(NeuralRenderer(H)).cuda()
-        dp_boundaries = torch.nn.DataParallel(L.Boundaries_Loss())
+    if extras and solo and a.tex:
+        # (device_ids: one process per GPU -- this process owns `dev` alone, whatever else the node shows; main.py's default
+        # of every visible device belongs to its one-process layout)
+        ids = [dev.index]
+        dp_renderer = torch.nn.DataParallel(NeuralRenderer(H), device_ids=ids).cuda()
+        dp_tex_renderer = torch.nn.DataParallel(NeuralRenderer(H), device_ids=ids).cuda()
+        dp_boundaries = torch.nn.DataParallel(L.Boundaries_Loss(), device_ids=ids)
 
         def reference_sequence():
             pred_v = solver(delta, mean_override=mean_p)
@@ -590,7 +609,7 @@ def run_config2_or_5(ctx):
 
     # ---- the metric string taken literally: silhouette render + backward alone (a3 fwd + bwd to vertices and
     # cameras, no losses, no texture branch); reported beside the headline step, never instead of it
-    if extras:
+    if extras and solo:
         rv = solver(delta0).detach().requires_grad_(True)
         rc = cams0.clone().requires_grad_(True)
         rw = torch.randn(N, H, H, device=dev) / (H * H)
@@ -610,7 +629,7 @@ def run_config2_or_5(ctx):
     # of the deformation system with learned handle weights (a8: cot Laplacian, fp64 Cholesky, lbs gradient)
     # + the mesh priors on the deformed shape (a14 locally_rigid_fn, a15 mesh_laplacian_smoothing 'cot');
     # reported beside the headline value, never instead of it
-    if a.tex and extras:
+    if a.tex and extras and solo:
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.loss import mesh_laplacian_smoothing
         from acfm_video_3d_reconstruction_amd.pytorch3d_shim.structures import Meshes
         lbs_p = torch.nn.Parameter(lbs_logits.clone())
@@ -882,8 +901,9 @@ def run_config4(ctx):
             cur.wait_stream(st)
     unpack_graph = [None]
 
-    def exchange(graph_ok=True):
-        SharedShapeExchange.reduce_many(exs)     # ONE all-reduce for the three templates
+    def exchange(graph_ok=True, collective=True):
+        if collective:
+            SharedShapeExchange.reduce_many(exs)     # ONE all-reduce for the three templates
         if graph_ok and unpack_graph[0] is not None:
             unpack_graph[0].replay()             # (a second small hipGraph behind the collective: the solve backwards)
         else:
@@ -906,6 +926,19 @@ def run_config4(ctx):
     dt = ctx.time_steps(step, a.warmup, a.steps)
     ops.invalidate_setups()
     legs = {}
+    if world > 1:   # the same step on every rank at once without the collective: the base of a weak-scaling ratio
+        def local_only():
+            if g is not None:
+                g.replay()
+            else:
+                compute()
+            exchange(graph_ok=g is not None, collective=False)
+        dt_local = ctx.time_steps(local_only, max(2, a.warmup // 2), a.steps)
+        legs["same_step_no_exchange"] = {
+            "value_per_gpu": round(N * a.steps / dt_local, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_local / a.steps, 4),
+            "note": "every rank runs this line's step without the all-reduce (max over ranks): n_gpus x value_per_gpu is what "
+                    "perfect weak scaling would give"}
+        ops.invalidate_setups()
     if not a.headline_only and g is not None:
         legs["eager_launch"] = ctx.leg(ctx.time_steps(eager, max(2, a.warmup // 2), a.steps), N, a.steps)
     kern = kernel_profile(ctx, eager, a.steps)
