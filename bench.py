@@ -71,6 +71,10 @@ def parse():
     p.add_argument("--tex-stream", type=int, default=0,
                    help="texture branch forked onto its own HIP stream behind the silhouette forward (graph edges in a capture); "
                         "measured: no gain, 0.693 vs 0.689 ms/step -- every kernel of either branch fills the chip")
+    p.add_argument("--bds-stream", type=int, default=0,
+                   help="boundary loss (projection hand-out, visibility, k_bds_loss and its backward) forked onto its own HIP "
+                        "stream beside the silhouette-loss pass and the texture branch; measured: no gain, 0.579 vs 0.570-0.576 "
+                        "ms/step -- a fork and a join in the graph cost more than the 15 us kernel they hide")
     return p.parse_args()
 
 
@@ -381,6 +385,7 @@ def run_config2_or_5(ctx):
     _flat, flat_views, flat_extra = reducer.packed(n_extra=1)
     params = [delta, cams, mean_p, atlas]
     side = torch.cuda.Stream(device=dev) if (a.tex and a.tex_stream) else None
+    bside = torch.cuda.Stream(device=dev) if a.bds_stream else None
     if cfg5:   # references and atlas held in half by the caller (what ACFM_STORE_F16 reads); the atlas gradient stays float
         gt_h, edt_h, imgs_h = gt_mask.half(), edt.half(), imgs_gt.half()
     seed = torch.ones((), device=dev)   # d total / d total, made once (autograd.grad would fill a fresh one every step)
@@ -407,10 +412,17 @@ def run_config2_or_5(ctx):
             with torch.cuda.stream(side):
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
                 tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)               # main.py:655-662
+        forked_bds = bside is not None and not fused
+        if forked_bds:   # the boundary loss beside everything up to the total (joined below)
+            bside.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(bside):
+                proj = ren.project_points(pred_v, cams)                      # a2
+                bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)        # a12
         if not fused:
             sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)   # a10, a11: [N,4] = (l1, ., ., edt)
-        proj = ren.project_points(pred_v, cams)                          # a2
-        bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
+        if not forked_bds:
+            proj = ren.project_points(pred_v, cams)                          # a2
+            bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)            # a12
         # total = mean_n(l1 + 0.1 edt + 0.1 bds) [+ 0.5 mean_n(texture mse)]: one launch each way
         # (combine_losses) instead of ~13 elementwise launches on 64-element vectors
         if side is not None:
@@ -422,7 +434,11 @@ def run_config2_or_5(ctx):
             else:
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
                 tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)                   # main.py:655-662
+            if forked_bds:
+                torch.cuda.current_stream(dev).wait_stream(bside)
             return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
+        if forked_bds:
+            torch.cuda.current_stream(dev).wait_stream(bside)
         return L.combine_losses([sil4, bdt], W_SIL + [0.1])
 
     # ---------------------------------------------------------------- shared = mean: fixed handle weights (config 2 as quoted)
