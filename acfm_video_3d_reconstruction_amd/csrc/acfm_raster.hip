@@ -593,10 +593,18 @@ __device__ __forceinline__ unsigned edge_cull4(const float4 a, const float4 b, f
 // EDGE_CULL pays for itself only where a kept pair is expensive (the K-nearest forward walk:
 // -4.5 %); the backward and nearest-face walks drop most pairs on a cheap key / depth compare and
 // were measured slower with it (+7 %, +2 %).
-template <bool EDGE_CULL, class LT, class Body>
+// SHARE (the backward): the four sub-lists are of different lengths (50 of 64 lanes have a face in an average
+// iteration), and a group that has run out used to idle until the longest list ended.  The groups are paired --
+// longest with shortest, the two middle ones -- and the shorter group of a pair, once through its own list, takes the
+// faces of its partner's list from the END, for the PARTNER's pixels (lane j of the helper stands in for lane j of the
+// partner: same face for the 16 lanes of a row, so the row reduction of the gradient is unchanged); the pair then needs
+// ceil((n_A + n_B) / 2) iterations instead of n_A.  prep(partner_lane) is called once per walk with the lane whose
+// pixel this lane takes over when it helps (-1: never); body gets (cand, in_box, ordinal, helping, xf, yf).
+struct NoPrep { __device__ __forceinline__ void operator()(int) const {} };
+template <bool EDGE_CULL, bool SHARE = false, class LT, class Body, class Prep = NoPrep>
 __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_n, float blur,
                                           unsigned char* wl /* [2 CAP], EDGE_CULL only */,
-                                          Body&& body) {
+                                          Body&& body, Prep&& prep = NoPrep()) {
   const int by = (t.yi & ~7), bx = (t.xi & ~7);
   const int grp = t.lane >> 4;
   // NDC extents (pixel centres) of the four 4x4 blocks: x by column pair, y by row pair
@@ -715,6 +723,52 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int my_n = (grp == 0) ? n0 : (grp == 1) ? n1 : (grp == 2) ? n2 : n3;
   const unsigned char* sub = sub0 + grp * LT::CAP;
+  if constexpr (SHARE) {
+    if (!split) {
+      // pairs (wave-uniform): a = the longest list, d = the shortest, b >= c the other two
+      int a = 0, na = n0;
+      if (n1 > na) { a = 1; na = n1; }
+      if (n2 > na) { a = 2; na = n2; }
+      if (n3 > na) { a = 3; na = n3; }
+      int d = a == 0 ? 1 : 0, nd = a == 0 ? n1 : n0;
+      if (a != 1 && n1 < nd) { d = 1; nd = n1; }
+      if (a != 2 && n2 < nd) { d = 2; nd = n2; }
+      if (a != 3 && n3 < nd) { d = 3; nd = n3; }
+      int b = -1, c = -1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (g != a && g != d) { if (b < 0) b = g; else c = g; }
+      int nb = b == 0 ? n0 : b == 1 ? n1 : b == 2 ? n2 : n3, nc = c == 0 ? n0 : c == 1 ? n1 : c == 2 ? n2 : n3;
+      if (nc > nb) { const int tg = b; b = c; c = tg; const int tn = nb; nb = nc; nc = tn; }
+      const int xa = (na + nd + 1) >> 1, xb = (nb + nc + 1) >> 1;   // the longer group of a pair keeps its first x faces
+      // per lane: own faces [0, own_n), then faces [h0, h0 + h_n) of group `pg`'s list for that group's pixels
+      const int own_n = grp == a ? xa : grp == b ? xb : my_n;
+      const int pg = grp == d ? a : grp == c ? b : -1;
+      const int h0 = grp == d ? xa : xb;
+      const int h_n = grp == d ? na - xa : grp == c ? nb - xb : 0;
+      const int n_it = max(xa, xb);
+      const int jj = t.lane & 15;
+      prep(pg >= 0 ? pg * 16 + jj : -1);
+      // the partner's pixel (4x4 block pg of the 8x8 block, same position inside it)
+      const int pyi = by + ((pg >= 0 ? pg : grp) >> 1) * 4 + (jj >> 2), pxi = bx + ((pg >= 0 ? pg : grp) & 1) * 4 + (jj & 3);
+      const float pxf = pix_to_ndc(H - 1 - pxi, H), pyf = pix_to_ndc(H - 1 - pyi, H);
+      const bool pvalid = (pyi < H) && (pxi < H);
+      const unsigned char* hsub = sub0 + (pg >= 0 ? pg : grp) * LT::CAP + h0;
+      for (int i = 0; i < n_it; ++i) {
+        const bool own = i < own_n;
+        const bool help = !own && (i - own_n) < h_n;
+        const int ci = own ? (int)sub[i] : (help ? (int)hsub[i - own_n] : 0);
+        const Cand cur = load_cand(L, ci);
+        const float exf = help ? pxf : t.xf, eyf = help ? pyf : t.yf;
+        const bool have = own || (help && pvalid);
+        const bool in_box = have && !((exf > cur.box.y) | (exf < cur.box.x) | (eyf > cur.box.w) | (eyf < cur.box.z));
+        DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(in_box))); DIAG_ADD(10, __popcll(__ballot(have)));
+        DIAG_ADD(12, __popcll(__ballot(have) & 0x0001000100010001ull));
+        body(cur, in_box, i, help, exf, eyf);
+      }
+      return;
+    }
+  }
   // a group that has run out of faces (or has none) keeps loading its last (or the tile's
   // first) record: harmless, the lanes are masked by `have`.  (Prefetching the next record one
   // iteration ahead was measured: +16 VGPRs, no change in time.)
@@ -727,6 +781,7 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
   // iteration is then one LDS round trip (the record) instead of two (sub-list byte -> record)
   int nxt = my_n > 0 ? (split ? grp : (int)sub[0]) : 0;
 #endif
+  if constexpr (SHARE) prep(-1);
   for (int i = 0; i < n_max; ++i) {
 #if ACFM_WALK_PREFETCH
     const int ci = nxt;
@@ -744,7 +799,8 @@ __device__ __forceinline__ void walk_wave(LT& L, const Tile& t, int H, int list_
         !((t.xf > cur.box.y) | (t.xf < cur.box.x) | (t.yf > cur.box.w) | (t.yf < cur.box.z));
     DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(in_box))); DIAG_ADD(10, __popcll(__ballot(have)));
     DIAG_ADD(12, __popcll(__ballot(have) & 0x0001000100010001ull));   // (group, face) pairs walked
-    body(cur, in_box, i);
+    if constexpr (SHARE) body(cur, in_box, i, false, t.xf, t.yf);
+    else body(cur, in_box, i);
   }
 }
 
@@ -1932,6 +1988,9 @@ __device__ __forceinline__ void acc_add_raw(float* p, float v) { atomicAdd(p, v)
 __device__ __forceinline__ void acc_add_raw(long long* p, long long v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
+#ifndef ACFM_BWD_SHARE
+#define ACFM_BWD_SHARE 1
+#endif
 template <class AccT>
 __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t, const void* __restrict__ mask,
                                               const unsigned long long* __restrict__ kth,
@@ -1973,9 +2032,26 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   if constexpr (sizeof(AccT) == 8) gout = reinterpret_cast<AccT*>(ws.grad_fix) + (size_t)t.n * V * 2;
   else gout = reinterpret_cast<AccT*>(ws.grad_ndc) + (size_t)t.n * V * 2;
 
+  // the pixel this lane stands in for when its group helps its partner group (walk_wave<.., SHARE>): that lane's
+  // gradient coefficient and K-th key, fetched once per walk
+  float coef_p = 0.f;
+  unsigned long long kth_p = KEY_NONE;
   bin_and_walk(ws, t, F, H, L, s_fl, 0.f, [&](int list_n) {
-    walk_wave<false>(L, t, H, list_n, blur, nullptr, [&](const Cand& cd, bool in_box, int ord) {
+#ifdef ACFM_DIAG_BWD_NO_WALK
+    if (list_n >= 0) return;
+#endif
+    walk_wave<false, ACFM_BWD_SHARE != 0>(L, t, H, list_n, blur, nullptr,
+#if ACFM_BWD_SHARE
+                                          [&](const Cand& cd, bool in_box, int ord, bool helping, float exf, float eyf) {
+      const float coef_e = helping ? coef_p : coef;
+      const unsigned long long kth_e = helping ? kth_p : kthkey;
+      bool member = (coef_e != 0.0f) && in_box;
+#else
+                                          [&](const Cand& cd, bool in_box, int ord) {
+      const float exf = t.xf, eyf = t.yf, coef_e = coef;
+      const unsigned long long kth_e = kthkey;
       bool member = work && in_box;
+#endif
       if (__ballot(member) == 0ull) return;
 #if ACFM_BWD_EDGE_GLOBAL
       const FaceRec& grec = ws.rec[(size_t)t.n * F + cd.fid];
@@ -1987,8 +2063,8 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       bool inside = false;
       // stage 1 (depth): only faces at or before the pixel's K-th kept face took part in the
       // blend; the others are dropped before their edge distances are computed
-      member = member && test_face_depth<false>(t.xf, t.yf, A, B, cd.c.x, cd.c.y, cd.rden, h, inside);
-      member = member && (make_key(h.pz, cd.fid) <= kthkey);
+      member = member && test_face_depth<false>(exf, eyf, A, B, cd.c.x, cd.c.y, cd.rden, h, inside);
+      member = member && (make_key(h.pz, cd.fid) <= kth_e);
       if (__ballot(member) == 0ull) return;
       float tpar[3] = {0.f, 0.f, 0.f};
 #if ACFM_BWD_EDGE_GLOBAL
@@ -1996,12 +2072,12 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
       // (L2-resident: 128 B x 1280 faces per mesh) instead of recomputing them per pixel; requested before the depth
       // stage so that its ~100 instructions cover the latency.  A face with a degenerate edge takes the unfactored path.
       if (__ballot(e1g.z != 0.0f) != 0ull) {
-        if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h, tpar);
+        if (member) member = test_face_dist(exf, eyf, A, B, blur, inside, h, tpar);
       } else {
-        if (member) member = test_face_dist_e(t.xf, t.yf, A, B, e0g, e1g, blur, inside, h, tpar);
+        if (member) member = test_face_dist_e(exf, eyf, A, B, e0g, e1g, blur, inside, h, tpar);
       }
 #else
-      if (member) member = test_face_dist(t.xf, t.yf, A, B, blur, inside, h, tpar);
+      if (member) member = test_face_dist(exf, eyf, A, B, blur, inside, h, tpar);
 #endif
       if (__ballot(member) == 0ull) return;
       float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
@@ -2010,7 +2086,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         // inside <=> sd < 0: an inside pixel lies on no edge, so d > 0 and sd = -d < 0
         const bool inside = h.sd < 0.0f;
         // (1-ulp reciprocal in the sigmoid: 1e-7 relative on a gradient checked to 1e-4)
-        const float gs = coef * sigmoid_neg_fast(h.sd, sigma, sig_scale);   // dL / d sd
+        const float gs = coef_e * sigmoid_neg_fast(h.sd, sigma, sig_scale);   // dL / d sd
         const float gd = inside ? -gs : gs;                      // sd = inside ? -d : d
         // the arg-min edge (01 first, then 02, then 12: SURVEY App-A.4), chosen with selects so that the
         // wave runs ONE distance backward instead of up to three divergent copies of it
@@ -2020,7 +2096,7 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
         const float bx = e01 ? x1 : x2, by = e01 ? y1 : y2;
         const float tq = e01 ? tpar[0] : (e02 ? tpar[1] : tpar[2]);
         float ax_, ay_, bx_, by_;
-        point_line_dist_bwd(t.xf, t.yf, ax, ay, bx, by, tq, gd, ax_, ay_, bx_, by_);
+        point_line_dist_bwd(exf, eyf, ax, ay, bx, by, tq, gd, ax_, ay_, bx_, by_);
         if (e01) { g0x = ax_; g0y = ay_; g1x = bx_; g1y = by_; }
         else if (e02) { g0x = ax_; g0y = ay_; g2x = bx_; g2y = by_; }
         else { g1x = ax_; g1y = ay_; g2x = bx_; g2y = by_; }
@@ -2047,8 +2123,21 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
           if (k2 != 0.f) acc_add(&acc[2], k2);
         }
       }
-    });
+    }
+#if ACFM_BWD_SHARE
+    , [&](int partner_lane) {
+      const int src = partner_lane >= 0 ? partner_lane : t.lane;
+      coef_p = __shfl(coef, src, 64);
+      const unsigned lo = (unsigned)__shfl((int)(unsigned)(kthkey & 0xffffffffull), src, 64);
+      const unsigned hi = (unsigned)__shfl((int)(unsigned)(kthkey >> 32), src, 64);
+      kth_p = ((unsigned long long)hi << 32) | lo;
+    }
+#endif
+    );
     wave_lds_sync();
+#ifdef ACFM_DIAG_BWD_NO_FLUSH
+    if (list_n >= 0) return;
+#endif
     for (int c = t.lane; c < list_n; c += RT) {
       AccT* acc = s_acc[c];
       const AccT z = (AccT)0;
@@ -2067,8 +2156,13 @@ __device__ __forceinline__ void sil_bwd_block(const RasterWs& ws, const Tile& t,
   });
 }
 
+// waves per SIMD the backward is compiled for: with the shared walk 5 (no spills; 156.9 us in the benchmark step) beats
+// 6 (80 VGPRs + 28 B of scratch; 160.5 us); without it 6 had measured best
+#ifndef ACFM_BWD_WAVES
+#define ACFM_BWD_WAVES 5
+#endif
 template <class AccT>
-__global__ __launch_bounds__(RT, 6) void k_sil_bwd(RasterWs ws, const void* __restrict__ mask,
+__global__ __launch_bounds__(RT, ACFM_BWD_WAVES) void k_sil_bwd(RasterWs ws, const void* __restrict__ mask,
                                                  const unsigned long long* __restrict__ kth,
                                                  BwdGrad grad_mask, int N, int V,
                                                  int F, int H, float blur, float sigma) {
