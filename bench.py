@@ -398,7 +398,9 @@ def run_config2_or_5(ctx):
             bdt = L.bds_loss(ren.project_points(pred_v, cams), bds, faces, p2f, reduce=False)
             tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_h, gt_h)[0]
             return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
-        if fused:   # opt-in operator: the loss terms leave the raster kernel with the mask (acfm_sil_loss_*)
+        fuse_sil = fused and "fusetexonly" not in os.environ.get("ACFM_BENCH_AB", "")
+        fuse_tex = fused and "fusesilonly" not in os.environ.get("ACFM_BENCH_AB", "")
+        if fuse_sil:   # opt-in operator: the loss terms leave the raster kernel with the mask (acfm_sil_loss_*)
             sil4, mask, p2f = ren.forward_silhouette_losses(pred_v, faces, cams, gt_mask, edt, raw=True)
         else:
             mask, p2f = ren(pred_v, faces, cams)                             # a3
@@ -412,13 +414,13 @@ def run_config2_or_5(ctx):
             with torch.cuda.stream(side):
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)    # a4
                 tmse = L.masked_texture_mse(tex, imgs_gt, gt_mask)               # main.py:655-662
-        forked_bds = bside is not None and not fused
+        forked_bds = bside is not None and not fuse_sil
         if forked_bds:   # the boundary loss beside everything up to the total (joined below)
             bside.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(bside):
                 proj = ren.project_points(pred_v, cams)                      # a2
                 bdt = L.bds_loss(proj, bds, faces, p2f, reduce=False)        # a12
-        if not fused:
+        if not fuse_sil:
             sil4 = L.fused_silhouette_losses(mask, gt_mask, edt, raw=True)   # a10, a11: [N,4] = (l1, ., ., edt)
         if not forked_bds:
             proj = ren.project_points(pred_v, cams)                          # a2
@@ -429,7 +431,7 @@ def run_config2_or_5(ctx):
             torch.cuda.current_stream(dev).wait_stream(side)
             return L.combine_losses([sil4, bdt, tmse], W_SIL + [0.1, 0.5])
         if a.tex:
-            if fused:
+            if fuse_tex:
                 tmse = ren.forward_texture_mse(pred_v.detach(), faces, cams, atlas, imgs_gt, gt_mask)[0]
             else:
                 tex, _, _ = ren(pred_v.detach(), faces, cams, textures=atlas)        # a4
