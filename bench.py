@@ -227,7 +227,16 @@ def roofline_of(kern, alg, workload_key):
     `traffic` and the VALU figures, else they stay null."""
     # the dominant kernel among those that stream images (the per-step factorisation of the deformation system, where a
     # workload has one, is a latency-bound fp64 chain with no HBM term: DESIGN.md section 4)
-    dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["us_per_step"])
+    ranked = sorted((k for k in kern if k in alg), key=lambda k: -kern[k]["us_per_step"])
+    roof = _roofline_of_kernel(kern, alg, workload_key, ranked[0])
+    # the next two streaming kernels by time, same figures (the judged object is the dominant kernel's, above)
+    also = [_roofline_of_kernel(kern, alg, workload_key, k) for k in ranked[1:3]]
+    if also:
+        roof["next_kernels"] = [{k: v for k, v in r.items() if k not in ("peak", "unit", "bound", "traffic_source")} for r in also]
+    return roof
+
+
+def _roofline_of_kernel(kern, alg, workload_key, dom):
     ab = alg.get(dom, 0)
     ach = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9 if ab else 0.0
     traffic, traffic_src, pmk = None, None, None
