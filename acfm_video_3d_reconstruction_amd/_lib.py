@@ -28,6 +28,7 @@ SIGNATURES = {
     "acfm_project_xy_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "acfm_deform_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "acfm_deform_apply_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "acfm_deform_presolve_sums_f64": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "acfm_correlation_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acfm_of_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acfm_of_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

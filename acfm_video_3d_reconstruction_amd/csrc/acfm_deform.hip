@@ -201,11 +201,63 @@ __global__ __launch_bounds__(64 * DM_WAVES) void k_deform_bwd_dm(const float* __
   gmean[i] = (s0 + s1) + (s2 + s3);
 }
 
+// G = sum_n g_n delta_n^T accumulated in DOUBLE (and sum_n g_n): the pre-solve sums that a sharded step exchanges.
+// d lbs = solve_backward(G) amplifies the rounding of G by the conditioning of the deformation system (~1e5), and a
+// float32 sum depends on how the frames are split over ranks; a double sum does not at float32's resolution, so the
+// exchanged buffer holds doubles and G is rounded to float32 ONCE, after the all-reduce -- the sharded and the
+// single-process step then hand the same bits to the solve's backward.  No atomics, fixed order.
+// One wave per (vertex, quarter of the handles): lane j takes the frames j, j + 64, ..., holds its g_n[v] in registers,
+// and the wave sums the 64 partial products of every handle of its quarter with a butterfly in double.
+constexpr int GP64_KQ = 4;   // handles per wave = ceil(K_h / GP64_KQ)
+__global__ __launch_bounds__(256) void k_deform_grad_P_f64(const float* __restrict__ g, const float* __restrict__ delta,
+                                                          int N, int V, int Kh, double* __restrict__ G64,
+                                                          float* __restrict__ G32, double* __restrict__ m64) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int v = wave / GP64_KQ, q = wave % GP64_KQ;
+  if (v >= V) return;                                   // (whole wave)
+  const int kq = (Kh + GP64_KQ - 1) / GP64_KQ, k0 = q * kq, k1 = min(Kh, k0 + kq);
+  if (m64 && q == GP64_KQ - 1) {                        // sum_n g_n[v] as well (the last quarter has the fewest handles)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int n = lane; n < N; n += 64) {
+      const float* gv = g + ((size_t)n * V + v) * 3;
+      a0 += (double)gv[0]; a1 += (double)gv[1]; a2 += (double)gv[2];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m, 64); a1 += __shfl_xor(a1, m, 64); a2 += __shfl_xor(a2, m, 64); }
+    if (lane == 0) { m64[(size_t)v * 3] = a0; m64[(size_t)v * 3 + 1] = a1; m64[(size_t)v * 3 + 2] = a2; }
+  }
+  for (int k = k0; k < k1; ++k) {
+    double a = 0.0;
+    for (int n = lane; n < N; n += 64) {
+      const float* gv = g + ((size_t)n * V + v) * 3;
+      const float* dk = delta + ((size_t)n * Kh + k) * 3;
+      a = fma((double)gv[0], (double)dk[0], a); a = fma((double)gv[1], (double)dk[1], a); a = fma((double)gv[2], (double)dk[2], a);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) {
+      G64[(size_t)v * Kh + k] = a;
+      if (G32) G32[(size_t)v * Kh + k] = (float)a;
+    }
+  }
+}
 }  // namespace acfm
 
 using namespace acfm;
 
 extern "C" {
+
+int acfm_deform_presolve_sums_f64(const float* delta, const float* grad_verts, int N, int V, int Kh, double* G64,
+                                  double* mean64, float* grad_P, void* stream) {
+  if (!delta || !grad_verts || !G64 || N <= 0 || V <= 0 || Kh <= 0 || N > 1000000 || (size_t)V * Kh > 0x7fffffffull)
+    return ACFM_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(ACFM_PROF_DEFORM_BWD, st);
+  hipLaunchKernelGGL(k_deform_grad_P_f64, dim3((unsigned)(((size_t)V * GP64_KQ + 3) / 4)), dim3(256), 0, st, grad_verts,
+                     delta, N, V, Kh, G64, grad_P, mean64);
+  ACFM_CHECK_LAUNCH();
+  return ACFM_OK;
+}
 
 int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, int N, int V, int Kh,
                       float* verts, void* stream) {

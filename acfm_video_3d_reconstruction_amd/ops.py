@@ -280,9 +280,43 @@ class _DeformApply(torch.autograd.Function):
         gd = torch.empty_like(d) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().acfm_deform_apply_backward(
-                _lib.ptr(p), _lib.ptr(d), _lib.ptr(g), N, V, Kh, _lib.ptr(gd), _lib.ptr(gm), _lib.ptr(gp),
+                _lib.ptr(p), _lib.ptr(d), _lib.ptr(g), N, V, Kh, _lib.ptr(gd), _lib.ptr(gm), None,
                 _lib.cur_stream(g.device)), "acfm_deform_apply_backward")
+            if gp is not None:
+                # dL/dP = sum_n g_n delta_n^T feeds the solve's backward, which amplifies its rounding by the conditioning
+                # of the system: summed in double and rounded once (acfm_deform_presolve_sums_f64), so that the value does
+                # not depend on how the frames are grouped; a frame-sharded step (sharding.SharedShapeExchange) takes the
+                # unrounded doubles for its exchange buffer
+                sink = _PRESOLVE_SINKS.get(p.data_ptr())
+                if sink is not None:       # (G [V,K_h], sum g [V,3]): float64 views INSIDE the exchange buffer
+                    g64, m64 = sink.presolve_buffer(V, Kh, g.device)
+                else:
+                    g64, m64 = torch.empty((V, Kh), dtype=torch.float64, device=g.device), None
+                _lib.check(_lib.lib().acfm_deform_presolve_sums_f64(
+                    _lib.ptr(d), _lib.ptr(g), N, V, Kh, _lib.ptr(g64), _lib.ptr(m64), _lib.ptr(gp), _lib.cur_stream(g.device)),
+                    "acfm_deform_presolve_sums_f64")
         return gm, gp, gd
+
+
+# P leaf (data_ptr) -> the object that wants the unrounded double sums of its backward (presolve_buffer(V, Kh, device)
+# -> persistent float64 tensors ([V,K_h], [V,3]) it will read after the backward).  One entry per live exchange.
+_PRESOLVE_SINKS = {}
+
+
+def register_presolve_sink(P, sink, previous_key=None):
+    """sharding.SharedShapeExchange.apply(): the backward of deform_apply(., P, .) writes sum_n g_n delta_n^T in double
+    into sink.presolve_buffer(...).  -> the key to hand back as previous_key next time (or to drop_presolve_sink)."""
+    with _LOCK:
+        if previous_key is not None:
+            _PRESOLVE_SINKS.pop(previous_key, None)
+        key = P.data_ptr()
+        _PRESOLVE_SINKS[key] = sink
+    return key
+
+
+def drop_presolve_sink(key):
+    with _LOCK:
+        _PRESOLVE_SINKS.pop(key, None)
 
 
 def deform_apply(mean_v, P, delta):

@@ -148,6 +148,36 @@ class SharedShapeExchange:
         self._flat = None
         self._P = self._P_leaf = self._mean_leaf = None
         self.bytes, self._n_sc, self._shapes = 0, 0, None
+        # the exchange buffer holds DOUBLES: G = sum g delta^T is summed in double on every rank (the deformation apply's
+        # backward writes it here, unrounded), across the ranks, and rounded to float once, behind the collective --
+        # d lbs = solve_backward(G) amplifies G's rounding by the conditioning of the system (~1e5), and this way the
+        # split of the frames over the ranks no longer shows in it
+        self._store, self._filled, self._sink_key = None, False, None
+
+    def _room(self, n, device):
+        """A persistent float64 allocation of at least n elements (the packed buffer is its head)."""
+        if self._store is None or self._store.numel() < n or self._store.device != device:
+            old = self._store
+            self._store = torch.zeros(max(n, 64), dtype=torch.float64, device=device)
+            if old is not None and old.device == device:
+                self._store[:old.numel()].copy_(old)
+        return self._store
+
+    def presolve_buffer(self, V, Kh, device):
+        """(called by ops._DeformApply.backward) where this step's local sums go: float64 views [V,K_h] and [V,3] at the
+        head of the exchange buffer -- the backward's kernel writes the packed layout itself."""
+        tail = sum(p.numel() for p in self.extra) + max(self._n_sc, 8)
+        st = self._room(V * Kh + 3 * V + tail, device)
+        self._filled = True
+        return st[:V * Kh].view(V, Kh), st[V * Kh:V * Kh + 3 * V].view(V, 3)
+
+    def __del__(self):
+        try:
+            if self._sink_key is not None:
+                from . import ops
+                ops.drop_presolve_sink(self._sink_key)
+        except Exception:
+            pass
 
     def apply(self, delta):
         """delta [n_local,K_h,3] -> pred_v [n_local,V,3]; one factorisation per call (lbs / mean shape may have moved)."""
@@ -156,40 +186,49 @@ class SharedShapeExchange:
         self._P = s.solve_matrix()                                   # carries the autograd path to lbs when it is learned
         self._P_leaf = self._P.detach().requires_grad_(True)
         self._mean_leaf = s.mean_v.detach().requires_grad_(True)
+        self._filled = False
         if delta.is_cuda:
             from . import ops
+            self._sink_key = ops.register_presolve_sink(self._P_leaf, self, self._sink_key)
             return ops.deform_apply(self._mean_leaf, self._P_leaf, delta)
         return self._mean_leaf[None] + torch.matmul(self._P_leaf[None], delta)
-
-    def _buffer(self, n, device):
-        if self._flat is None or self._flat.numel() != n or self._flat.device != device:
-            self._flat = torch.zeros(n, dtype=torch.float32, device=device)
-        return self._flat
 
     # finish() = pack() -> reduce() -> unpack(); the three stages are public so that a step replayed from a hipGraph can
     # capture pack() (the last launches of the local backward) and run the collective + the solve's backward after the
     # replay (bench.py --gpus N), and so that several exchanges -- one per template of a mixed batch, BASELINE config 4
     # -- can share ONE collective (finish_many).
     def pack(self, gP=None, gmean=None, extra_scalars=None):
-        """Write [G | sum g | extra shared grads | scalars] into the persistent flat buffer (one torch.cat launch).
-        gP / gmean default to the .grad of the (P, mean) leaves of the last apply()."""
+        """Complete [G | sum g | extra shared grads | scalars] in the persistent float64 buffer.  On the GPU the first two
+        parts are there already (the deformation apply's backward writes its double sums in place: presolve_buffer);
+        otherwise gP / gmean -- by default the .grad of the (P, mean) leaves of the last apply() -- are copied in."""
         s = self.solver
         if gP is None:
             gP = self._P_leaf.grad if self._P_leaf.grad is not None else torch.zeros_like(self._P_leaf)
         if gmean is None:
             gmean = self._mean_leaf.grad if self._mean_leaf.grad is not None else torch.zeros_like(self._mean_leaf)
-        if s.mean_v.requires_grad and s.mean_v.grad is not None:       # the direct paths (priors on the template)
-            gmean = gmean + s.mean_v.grad
-        parts = [gP.reshape(-1), gmean.reshape(-1)]
-        parts += [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.extra]
+        direct = s.mean_v.grad if (s.mean_v.requires_grad and s.mean_v.grad is not None) else None   # priors on the template
         self._n_sc = 0 if extra_scalars is None else extra_scalars.numel()
+        nP, nm = gP.numel(), gmean.numel()
+        n = nP + nm + sum(p.numel() for p in self.extra) + self._n_sc
+        filled = self._filled and self._store is not None and self._store.device == gP.device
+        flat = self._room(n, gP.device)[:n]
+        if filled:
+            # the deformation apply's backward wrote G and sum g in double at the head of the buffer already (GPU); only a
+            # direct term on the mean shape (a prior on the template) is still to be added
+            if direct is not None:
+                flat[nP:nP + nm].add_(direct.reshape(-1))
+        else:
+            flat[:nP].copy_(gP.reshape(-1))
+            flat[nP:nP + nm].copy_((gmean if direct is None else gmean + direct).reshape(-1))
+        o = nP + nm
+        for p in self.extra:
+            flat[o:o + p.numel()].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+            o += p.numel()
         if self._n_sc:
-            parts.append(extra_scalars.detach().reshape(-1).float())
-        n = sum(p.numel() for p in parts)
-        flat = self._buffer(n, gP.device)
-        torch.cat(parts, out=flat)
+            flat[o:o + self._n_sc].copy_(extra_scalars.detach().reshape(-1))
+        self._flat = flat
         self._shapes = (tuple(gP.shape), tuple(gmean.shape))
-        self.bytes = 4 * n
+        self.bytes = 8 * n
         return flat
 
     def reduce(self, flat=None):
@@ -222,7 +261,7 @@ class SharedShapeExchange:
         o = 1
         for d in pshape:
             o *= d
-        G = flat[:o].view(pshape)
+        G = flat[:o].view(pshape).to(s.lbs.dtype if s.lbs.is_floating_point() else torch.float32, copy=True)   # the ONE rounding of G
         if s.lbs.requires_grad:
             direct, s.lbs.grad = s.lbs.grad, None                     # a direct term on lbs (a regulariser: replicated,
             # identical on every rank) is kept, like mean_v's; d lbs through P = solve_backward(G), on every rank.
@@ -233,12 +272,12 @@ class SharedShapeExchange:
         for d in mshape:
             nm *= d
         if s.mean_v.requires_grad:
-            s.mean_v.grad = flat[o:o + nm].view(mshape).clone()
+            s.mean_v.grad = flat[o:o + nm].view(mshape).to(s.mean_v.dtype, copy=True)
         o += nm
         for p in self.extra:
-            p.grad = flat[o:o + p.numel()].view_as(p).clone()
+            p.grad = flat[o:o + p.numel()].view_as(p).to(p.dtype, copy=True)
             o += p.numel()
-        return flat[flat.numel() - self._n_sc:].clone() if self._n_sc else None
+        return flat[flat.numel() - self._n_sc:].to(torch.float32, copy=True) if self._n_sc else None
 
     def finish(self, extra_scalars=None):
         self.pack(extra_scalars=extra_scalars)
@@ -256,7 +295,7 @@ class SharedShapeExchange:
         flats = [ex._flat for ex in exchanges]
         n = sum(f.numel() for f in flats)
         if getattr(head, "_joint", None) is None or head._joint.numel() != n or head._joint.device != flats[0].device:
-            head._joint = torch.zeros(n, dtype=torch.float32, device=flats[0].device)
+            head._joint = torch.zeros(n, dtype=flats[0].dtype, device=flats[0].device)
         joint = head._joint
         torch.cat(flats, out=joint)
         # (scalars sit inside the joint buffer, at the end of each exchange's part: reduce everything as sums here and
@@ -273,7 +312,7 @@ class SharedShapeExchange:
                 part[:f.numel() - ex._n_sc].div_(world)
             f.copy_(part)
             o += f.numel()
-        head.bytes = 4 * n
+        head.bytes = joint.element_size() * n
 
     @staticmethod
     def finish_many(exchanges, extra_scalars=None):

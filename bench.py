@@ -494,7 +494,7 @@ def run_config2_or_5(ctx):
 
     def exchange_shape(outs, graph_ok=True, collective=True):
         if collective:
-            ex.reduce()      # ONE all-reduce (RCCL) of ~49 KB
+            ex.reduce()      # ONE all-reduce (RCCL) of ~98 KB (the pre-solve sums in double)
         # d lbs = solve_backward(G) on every rank (acfm_deform_solve_backward) + the mean-shape gradient: a second small
         # hipGraph behind the collective when the step is replayed (the three launches + two copies are ~0.1 ms of host
         # time when issued from Python)

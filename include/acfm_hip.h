@@ -113,6 +113,14 @@ int acfm_deform_apply(const float* mean_v, const float* P, const float* delta, i
                       float* verts, void* stream);
 int acfm_deform_apply_backward(const float* P, const float* delta, const float* grad_verts, int N, int V,
                                int Kh, float* grad_delta, float* grad_mean, float* grad_P, void* stream);
+/* The pre-solve sums of a frame-sharded step in double (the buffer [G = sum_n g_n delta_n^T | sum_n g_n | ..]
+ * that the ranks all-reduce): G64 [V,K_h] and, optionally, mean64 [V,3], accumulated in double in a fixed order;
+ * grad_P (optional) = G64 rounded to float, the same figure acfm_deform_apply_backward's grad_P approximates in
+ * float arithmetic.  d lbs = acfm_deform_solve_backward(G) amplifies the rounding of G by the conditioning of the
+ * system: with doubles through the exchange and ONE rounding behind it, the split of the frames over the ranks no
+ * longer shows in the handle-weight gradient. */
+int acfm_deform_presolve_sums_f64(const float* delta, const float* grad_verts, int N, int V, int Kh, double* G64,
+                                  double* mean64, float* grad_P, void* stream);
 
 /* ---- correlation cost volume (forward only) ----------------------------------------------
  * replaces correlation_cuda.forward as MaskFlownet calls it (multiframe/data/optical_flow/model/

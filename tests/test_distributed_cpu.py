@@ -156,7 +156,7 @@ def test_lbs_gradient_through_the_presolve_exchange(tmp_path):
     s0, e0 = frame_shard(clips, T, 0, 2)
     np.testing.assert_allclose(got["delta"].numpy(), d_all.grad[s0:e0].numpy(), rtol=1e-5, atol=1e-6)
     V, Kh = lbs.shape
-    assert got["bytes"] == 4 * (V * Kh + 3 * V + 5 + 1)           # [G | sum g | extra | loss]: ~23 KB here, ~50 KB at K_h = 16
+    assert got["bytes"] == 8 * (V * Kh + 3 * V + 5 + 1)           # [G | sum g | extra | loss] in double: ~46 KB here, ~98 KB at K_h = 16
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -236,4 +236,4 @@ def test_mixed_templates_share_one_collective(tmp_path):
     s0, e0 = frame_shard(clips, T, 0, 2)
     np.testing.assert_allclose(got["delta"].numpy(), d_all.grad[s0:e0].numpy(), rtol=1e-5, atol=1e-6)
     V, Kh = tm[0][2].shape
-    assert got["bytes"] == 4 * (2 * (V * Kh + 3 * V) + 1)           # both templates' [G | sum g] + the loss scalar, one buffer
+    assert got["bytes"] == 8 * (2 * (V * Kh + 3 * V) + 1)           # both templates' [G | sum g] + the loss scalar, one buffer
