@@ -558,7 +558,9 @@ def run_config2_or_5(ctx):
     if extras:
         # the other launch mode of the same step, reported beside the headline (never instead of it)
         fn, _ = make_step(headline_shape, use_graph=not graphed)
-        legs["hipgraph_replay" if not graphed else "eager_launch"] = ctx.leg(ctx.time_steps(fn, half_w, a.steps), N, a.steps)
+        # (eager launches settle late: 0.64 ms per step over 30 steps, 0.58 over 200 -- the allocator's and the host's warm-up)
+        es = max(a.steps, 100)
+        legs["hipgraph_replay" if not graphed else "eager_launch"] = ctx.leg(ctx.time_steps(fn, max(half_w, 10), es), N, es)
         # the other choice of shared parameters, same run: with --gpus 1 this is the step --gpus N > 1 times per GPU
         # (the base of a like-for-like scaling ratio); with --gpus N the mean-only exchange of rounds 1-2
         fn, g_ok = make_step(not headline_shape, use_graph=use_graph)
