@@ -75,6 +75,7 @@ struct RasterWs {
   float* grad_ndc; // [N,V,2]
   long long* grad_fix; // [N,V,2] the same in 2^-36 fixed point (deterministic backward)
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
+  int* tile_part;  // [4,N,blocks^2] the same per face slice of k_setup (counters in LDS): k_order adds them into tile_cnt
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
   uint8_t* fvis;   // [N,F] 1 = the face is the nearest one at some pixel of the last texture render on this workspace
   int* n_work;     // [8] per XCD group: entries of its order that have work (the flagged-empty ones follow them)
@@ -142,6 +143,7 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
   w.grad_fix = (long long*)(p + o); o += align256(sizeof(long long) * 2 * (size_t)N * V);
   const size_t tt = (size_t)((H + 7) / 8) * ((H + 7) / 8);  // 8x8-pixel blocks (RBLK)
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
+  w.tile_part = (int*)(p + o);  o += align256(sizeof(int) * 4 * (size_t)N * tt);
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
   w.n_work = (int*)(p + o);     o += align256(sizeof(int) * 8);
   w.fvis = (uint8_t*)(p + o);   o += align256((size_t)N * F);

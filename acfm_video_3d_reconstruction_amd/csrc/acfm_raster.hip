@@ -210,31 +210,8 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
             else atomicOr(&g_mask[(size_t)row * mwords + (f >> 5)], bit);
           }
         // cost estimate for heavy-first scheduling: +1 on every 8x8 block the box may touch.  With the counters in LDS
-        // (images up to 512^2) slice 0 counts ALL faces of the mesh (below) and stores the result: no zero fill of
-        // ws.tile_cnt, no global atomics; larger images: every slice adds its faces to the zeroed array
-        if (!lds_cnt || slice == 0) count_box(xa, ya, xb, yb);
-      }
-    }
-  }
-  if (lds_cnt && slice == 0) {
-    // the faces of the other three slices: box and pixel range again (k_setup's own expressions), counters only
-    for (int f = f_hi + tid; f < F; f += TPB) {
-      const int64_t* fi = faces + ((size_t)n * F + f) * 3;
-      int i0 = (int)fi[0], i1 = (int)fi[1], i2 = (int)fi[2];
-      i0 = min(max(i0, 0), V - 1); i1 = min(max(i1, 0), V - 1); i2 = min(max(i2, 0), V - 1);
-      const float x0 = s_v[3 * i0], y0 = s_v[3 * i0 + 1], x1 = s_v[3 * i1], y1 = s_v[3 * i1 + 1];
-      const float x2 = s_v[3 * i2], y2 = s_v[3 * i2 + 1];
-      const float area = edge_fn(x2, y2, x0, y0, x1, y1);
-      if (area <= ACFM_K_EPS && area >= -1.0f * ACFM_K_EPS) continue;
-      const float b_x = min3f(x0, x1, x2) - margin, b_y = max3f(x0, x1, x2) + margin;
-      const float b_z = min3f(y0, y1, y2) - margin, b_w = max3f(y0, y1, y2) + margin;
-      const float hf = (float)H;
-      int xa = (int)floorf(hf - 1.0f - ((b_y + 1.0f) * hf - 1.0f) * 0.5f) - 1;
-      int xb = (int)ceilf(hf - 1.0f - ((b_x + 1.0f) * hf - 1.0f) * 0.5f) + 1;
-      int ya = (int)floorf(hf - 1.0f - ((b_w + 1.0f) * hf - 1.0f) * 0.5f) - 1;
-      int yb = (int)ceilf(hf - 1.0f - ((b_z + 1.0f) * hf - 1.0f) * 0.5f) + 1;
-      if (xb >= 0 && yb >= 0 && xa < H && ya < H) {
-        xa = max(xa, 0); ya = max(ya, 0); xb = min(xb, H - 1); yb = min(yb, H - 1);
+        // (images up to 512^2) every slice counts its own faces and stores its plane of ws.tile_part (k_order adds the
+        // four planes): no zero fill, no global atomics; larger images: every slice adds its faces to the zeroed ws.tile_cnt
         count_box(xa, ya, xb, yb);
       }
     }
@@ -244,8 +221,8 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   if ((tid & 63) == 0) { s_red[w][0] = bx0; s_red[w][1] = bx1; s_red[w][2] = by0; s_red[w][3] = by1; }
   const int any_big = __syncthreads_or(big) ? 1 : 0;  // (also the barrier before the copies below)
   if (lds_cnt) {
-    if (slice == 0)
-      for (int i = tid; i < tt_; i += TPB) ws.tile_cnt[(size_t)n * tt_ + i] = s_cnt[i] + any_big;   // all faces: plain stores
+    int* part = ws.tile_part + ((size_t)slice * gridDim.x + n) * tt_;
+    for (int i = tid; i < tt_; i += TPB) part[i] = s_cnt[i] + any_big;   // this slice's faces: plain stores
   } else {
     for (int i = tid; i < tt_; i += TPB)                // ws.tile_cnt was zeroed by the host
       if (any_big) atomicAdd(&ws.tile_cnt[(size_t)n * tt_ + i], any_big);
@@ -330,6 +307,8 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
   static_assert(CNT_TILE == RBLK, "cost counters are per raster block");
   const int m_first = (int)threadIdx.x / tt, bl_first = (int)threadIdx.x % tt;
   constexpr int OCH = 8;   // entries per thread whose cost loads are in flight together
+  static_assert(SETUP_SLICES == 4, "k_order adds four planes of ws.tile_part");
+  const bool parts = tt <= SETUP_LDS_TILES;   // k_setup kept its counters in LDS: one plane per face slice
   int cnt[NCLASS];
 #pragma unroll
   for (int c = 0; c < NCLASS; ++c) cnt[c] = 0;
@@ -341,7 +320,17 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
 #pragma unroll
     for (int u = 0; u < OCH; ++u) {
       const int e = (it0 + u) * blockDim.x + threadIdx.x;
-      cst[u] = (it0 + u < iters && e < per) ? ws.tile_cnt[(size_t)(m1 * G + g) * tt + bl1] : -1;
+      cst[u] = -1;
+      if (it0 + u < iters && e < per) {
+        const size_t o = (size_t)(m1 * G + g) * tt + bl1;
+        if (parts) {   // the four face slices' planes (k_setup); the sum is kept for the later readers (k_tex_cover)
+          const size_t plane = (size_t)N * tt;
+          cst[u] = (ws.tile_part[o] + ws.tile_part[plane + o]) + (ws.tile_part[2 * plane + o] + ws.tile_part[3 * plane + o]);
+          ws.tile_cnt[o] = cst[u];
+        } else {
+          cst[u] = ws.tile_cnt[o];
+        }
+      }
       bl1 += blockDim.x;
       while (bl1 >= tt) { bl1 -= tt; ++m1; }
       if (it0 == 0) cst0[u] = cst[u];
@@ -2649,7 +2638,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
                      (lds_mask ? slice_mask_bytes : 0);
   if (lds > 150 * 1024) return ACFM_E_BADARG;
   if (!lds_mask && zero_async(ws.cmask, sizeof(unsigned) * (size_t)N * ctiles * ctiles * mwords, st)) return ACFM_E_LAUNCH;
-  // (counters in LDS: slice 0 of k_setup stores the counts of all faces, nothing to zero)
+  // (counters in LDS: every slice of k_setup stores its own plane of ws.tile_part, nothing to zero)
   if (tt > SETUP_LDS_TILES && zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
   hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
