@@ -75,7 +75,8 @@ struct RasterWs {
   float* grad_ndc; // [N,V,2]
   long long* grad_fix; // [N,V,2] the same in 2^-36 fixed point (deterministic backward)
   int* tile_cnt;   // [N,blocks^2] faces whose box meets the 8x8 block (cost estimate for scheduling)
-  int* tile_part;  // [4,N,blocks^2] the same per face slice of k_setup (counters in LDS): k_order adds them into tile_cnt
+  int* tile_part;  // [slices,N,blocks^2] the same per face slice of k_setup (counters in LDS): k_order adds them into tile_cnt
+  int slices;      // face slices (workgroups) per mesh in k_setup: 4, 8 or 16
   int* order;      // [N*blocks^2] heavy-first visiting order of (mesh, block) per XCD group
   uint8_t* fvis;   // [N,F] 1 = the face is the nearest one at some pixel of the last texture render on this workspace
   int* n_work;     // [8] per XCD group: entries of its order that have work (the flagged-empty ones follow them)
@@ -133,17 +134,21 @@ static inline RasterWs carve_ws(void* base, int N, int V, int F, int H, int g_sp
     else if (g_split_mode > 0 || blocks <= 40960) w.split_slots = per_group * 32 < 1024 ? per_group * 32 : 1024;
     else w.split_slots = per_group * 4 < 256 ? per_group * 4 : 256;
   }
+  // face slices per mesh of k_setup (one workgroup each): enough workgroups to cover the chip with few meshes -- 4 at
+  // >= 64 meshes, 8 at >= 32, else 16 -- but at least 64 faces per slice
+  w.slices = N >= 64 ? 4 : N >= 32 ? 8 : 16;
+  while (w.slices > 4 && (F + w.slices - 1) / w.slices < 64) w.slices >>= 1;
   char* p = (char*)base;
   size_t o = 0;
   w.ndc = (float*)(p + o);      o += align256(sizeof(float) * 3 * (size_t)N * V);
   w.rec = (FaceRec*)(p + o);    o += align256(sizeof(FaceRec) * (size_t)N * F);
   w.vidx = (int4*)(p + o);      o += align256(sizeof(int4) * (size_t)N * F);
-  w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * 4 * (size_t)N);
+  w.mbox = (float4*)(p + o);    o += align256(sizeof(float4) * (size_t)w.slices * (size_t)N);
   w.grad_ndc = (float*)(p + o); o += align256(sizeof(float) * 2 * (size_t)N * V);
   w.grad_fix = (long long*)(p + o); o += align256(sizeof(long long) * 2 * (size_t)N * V);
   const size_t tt = (size_t)((H + 7) / 8) * ((H + 7) / 8);  // 8x8-pixel blocks (RBLK)
   w.tile_cnt = (int*)(p + o);   o += align256(sizeof(int) * (size_t)N * tt);
-  w.tile_part = (int*)(p + o);  o += align256(sizeof(int) * 4 * (size_t)N * tt);
+  w.tile_part = (int*)(p + o);  o += align256(sizeof(int) * (size_t)w.slices * (size_t)N * tt);
   w.order = (int*)(p + o);      o += align256(sizeof(int) * (size_t)N * tt);
   w.n_work = (int*)(p + o);     o += align256(sizeof(int) * 8);
   w.fvis = (uint8_t*)(p + o);   o += align256((size_t)N * F);

@@ -78,16 +78,16 @@ constexpr int FLCAP = 512;    // LDS face-id list of one wave (faces of its coar
 // ------------------------------------------------------------------------------- setup
 // mode 0: verts are world coordinates -> project with cams, flip y   (nmr.py:145-149)
 // mode 1: verts are already projected, no y flip                     (nmr.py:224-238)
-// Grid (N, SETUP_SLICES): every workgroup projects the mesh's V vertices into LDS (cheap, and it
+// Grid (N, ws.slices): every workgroup projects the mesh's V vertices into LDS (cheap, and it
 // keeps the slices independent) and handles one slice of the faces; slice boundaries are multiples
 // of 64 faces, so each slice owns whole words of the coarse masks and builds them in LDS without
 // talking to the others.  Tile counters are summed into zeroed memory with global atomics, the
 // mesh box is left as one box per slice (the raster kernels take the union of the four).
-constexpr int SETUP_SLICES = 4;
-__host__ __device__ __forceinline__ int setup_slice_faces(int F) {
-  return ((F + SETUP_SLICES - 1) / SETUP_SLICES + 63) / 64 * 64;
+__host__ __device__ __forceinline__ int setup_slice_faces(int F, int slices) {
+  return ((F + slices - 1) / slices + 63) / 64 * 64;
 }
 
+template <int SLICES>   // face slices per mesh (grid y): 4, 8 or 16 -- a template so that the slice arithmetic stays compile-time
 __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
                                                const int64_t* __restrict__ faces,
                                                const float* __restrict__ cams, int V, int F, int H,
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
   int* s_cnt = reinterpret_cast<int*>(s_v + 3 * V);
   if (lds_cnt)
     for (int i = tid; i < tt_; i += TPB) s_cnt[i] = 0;
-  const int q = setup_slice_faces(F);
+  const int q = setup_slice_faces(F, SLICES);
   const int f_lo = slice * q, f_hi = min(F, f_lo + q);
   // coarse face masks: bit f of row (cty, ctx) <=> the box of face f may touch that CTILE x CTILE tile
   const int ctiles_ = (H + CTILE - 1) / CTILE, mwords = 2 * ((F + 63) / 64);  // u32 words per row
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(TPB) void k_setup(const float* __restrict__ verts,
       bx0 = fminf(bx0, s_red[i][0]); bx1 = fmaxf(bx1, s_red[i][1]);
       by0 = fminf(by0, s_red[i][2]); by1 = fmaxf(by1, s_red[i][3]);
     }
-    ws.mbox[(size_t)n * SETUP_SLICES + slice] = make_float4(bx0, bx1, by0, by1);
+    ws.mbox[(size_t)n * SLICES + slice] = make_float4(bx0, bx1, by0, by1);
   }
 }
 
@@ -293,6 +293,7 @@ __device__ __forceinline__ int block_cost(const RasterWs& ws, int n, int bl, int
   const int by = bl / blocks, bx = bl % blocks;
   return ws.tile_cnt[((size_t)n * tiles + by * RBLK / CNT_TILE) * tiles + bx * RBLK / CNT_TILE];
 }
+template <bool MORE>   // MORE: k_setup ran 8 or 16 face slices per mesh (few meshes); false: the usual four
 __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int H, int g_split_dev) {
   // counting sort by cost class without atomics: every wave counts its entries per class (ballots,
   // wave-uniform counters), the counts are prefix-summed over (class, wave), and every wave then
@@ -306,8 +307,20 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
   // (m, bl) advance with e: no integer divisions in the loops (they were 2000 VALU instructions per wave).
   static_assert(CNT_TILE == RBLK, "cost counters are per raster block");
   const int m_first = (int)threadIdx.x / tt, bl_first = (int)threadIdx.x % tt;
+  if constexpr (MORE) {
+    // the mesh boxes: k_setup left one box per face slice; the raster kernels test a block against the mesh's box: with
+    // more than four slices it is joined here, once, into the first slot
+    for (int m = threadIdx.x; m < N / G; m += blockDim.x) {
+      float4* mb = ws.mbox + (size_t)(m * G + g) * ws.slices;
+      float4 u = mb[0];
+      for (int i = 1; i < ws.slices; ++i) {
+        const float4 m2 = mb[i];
+        u.x = fminf(u.x, m2.x); u.y = fmaxf(u.y, m2.y); u.z = fminf(u.z, m2.z); u.w = fmaxf(u.w, m2.w);
+      }
+      mb[0] = u;
+    }
+  }
   constexpr int OCH = 8;   // entries per thread whose cost loads are in flight together
-  static_assert(SETUP_SLICES == 4, "k_order adds four planes of ws.tile_part");
   const bool parts = tt <= SETUP_LDS_TILES;   // k_setup kept its counters in LDS: one plane per face slice
   int cnt[NCLASS];
 #pragma unroll
@@ -326,6 +339,10 @@ __global__ __launch_bounds__(1024) void k_order(RasterWs ws, int N, int tt, int 
         if (parts) {   // the four face slices' planes (k_setup); the sum is kept for the later readers (k_tex_cover)
           const size_t plane = (size_t)N * tt;
           cst[u] = (ws.tile_part[o] + ws.tile_part[plane + o]) + (ws.tile_part[2 * plane + o] + ws.tile_part[3 * plane + o]);
+          if constexpr (MORE)
+            for (int sl = 4; sl < ws.slices; sl += 4)     // 8 or 16 planes
+              cst[u] += (ws.tile_part[sl * plane + o] + ws.tile_part[(sl + 1) * plane + o]) +
+                        (ws.tile_part[(sl + 2) * plane + o] + ws.tile_part[(sl + 3) * plane + o]);
           ws.tile_cnt[o] = cst[u];
         } else {
           cst[u] = ws.tile_cnt[o];
@@ -825,11 +842,14 @@ __device__ __forceinline__ void bin_and_walk(const RasterWs& ws, const Tile& t, 
   if (t.empty) return;  // flagged by k_order: no face box near this block
 #if ACFM_MBOX_TEST
   {
-  float4 mb = ws.mbox[(size_t)t.n * SETUP_SLICES];
+  // the mesh's box: the four slices' boxes (the usual case), or slot 0 where k_order joined 8 or 16 of them
+  float4 mb = ws.mbox[(size_t)t.n * ws.slices];
+  if (ws.slices == 4) {
 #pragma unroll
-  for (int i = 1; i < SETUP_SLICES; ++i) {
-    const float4 m2 = ws.mbox[(size_t)t.n * SETUP_SLICES + i];
-    mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
+    for (int i = 1; i < 4; ++i) {
+      const float4 m2 = ws.mbox[(size_t)t.n * 4 + i];
+      mb.x = fminf(mb.x, m2.x); mb.y = fmaxf(mb.y, m2.y); mb.z = fminf(mb.z, m2.z); mb.w = fmaxf(mb.w, m2.w);
+    }
   }
   if (t.t_xmin > mb.y || t.t_xmax < mb.x || t.t_ymin > mb.w || t.t_ymax < mb.z) return;
   }
@@ -2631,7 +2651,7 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   const int blocks = (H + RBLK - 1) / RBLK;
   const int ctiles = (H + CTILE - 1) / CTILE;
   const size_t mwords = 2 * (((size_t)F + 63) / 64);
-  const size_t slice_words = (size_t)setup_slice_faces(F) / 32;
+  const size_t slice_words = (size_t)setup_slice_faces(F, ws.slices) / 32;
   const size_t slice_mask_bytes = sizeof(unsigned) * (size_t)ctiles * ctiles * (slice_words < mwords ? slice_words : mwords);
   const bool lds_mask = slice_mask_bytes <= (size_t)SETUP_LDS_MASK_BYTES;
   const size_t lds = sizeof(float) * 3 * (size_t)V + (tt <= SETUP_LDS_TILES ? sizeof(int) * (size_t)tt : 0) +
@@ -2641,9 +2661,18 @@ static int launch_setup(const float* verts, const int64_t* faces, const float* c
   // (counters in LDS: every slice of k_setup stores its own plane of ws.tile_part, nothing to zero)
   if (tt > SETUP_LDS_TILES && zero_async(ws.tile_cnt, sizeof(int) * (size_t)N * tt, st)) return ACFM_E_LAUNCH;
   ProfScope ps(ACFM_PROF_SETUP, st);
-  hipLaunchKernelGGL(k_setup, dim3(N, SETUP_SLICES), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
-                     margin, ws, vis, proj_xy);
-  hipLaunchKernelGGL(k_order, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, tn.split);
+  switch (ws.slices) {
+    case 4: hipLaunchKernelGGL(k_setup<4>, dim3(N, 4), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
+                               margin, ws, vis, proj_xy); break;
+    case 8: hipLaunchKernelGGL(k_setup<8>, dim3(N, 8), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
+                               margin, ws, vis, proj_xy); break;
+    default: hipLaunchKernelGGL(k_setup<16>, dim3(N, 16), dim3(TPB), lds, st, verts, faces, cams, V, F, H, offset_z, mode,
+                                margin, ws, vis, proj_xy); break;
+  }
+  if (ws.slices > 4)
+    hipLaunchKernelGGL(k_order<true>, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, tn.split);
+  else
+    hipLaunchKernelGGL(k_order<false>, dim3((N & 7) == 0 ? 8 : 1), dim3(1024), 0, st, ws, N, blocks * blocks, H, tn.split);
   ACFM_CHECK_LAUNCH();
   return ACFM_OK;
 }
