@@ -227,13 +227,38 @@ __global__ __launch_bounds__(LTPB) void k_bds_loss(const float* __restrict__ ver
   float best = 1000.0f;  // loss_utils.py:228: invisible vertices sit at distance 1000
   int bi = -1;
   const int chunk = (V + 3) / 4, v0 = wv * chunk, v1 = min(V, v0 + chunk);
+  // The wave's quarter of the vertices is packed IN PLACE to its visible ones (half of a closed mesh is never seen):
+  // 64 vertices a round, every lane reads its vertex before any lane writes, a kept vertex moves to a position at or
+  // before its own, order kept -- so the first nearest vertex still wins; s_idx remembers where it came from.
+  int* s_idx = reinterpret_cast<int*>(s_xy + 2 * (size_t)V);
+  int nvis = 0;
+  {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = v0; base < v1; base += 64) {
+      const int v = base + lane;
+      float2 q = make_float2(__builtin_inff(), 0.f);
+      if (v < v1) q = *reinterpret_cast<const float2*>(s_xy + 2 * v);
+      const bool keep = (v < v1) && !(q.x == __builtin_inff());
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int pos = v0 + nvis + __popcll(m & lt);
+        *reinterpret_cast<float2*>(s_xy + 2 * pos) = q;
+        s_idx[pos] = v;
+      }
+      nvis += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 #pragma unroll 8
-  for (int v = v0; v < v1; ++v) {
+  for (int v = v0; v < v0 + nvis; ++v) {
     const float2 q = *reinterpret_cast<const float2*>(s_xy + 2 * v);
     const float dx = bx - q.x, dy = by - q.y;
     const float d = dx * dx + dy * dy;
     if (d < best) { best = d; bi = v; }
   }
+  if (bi >= 0) bi = s_idx[bi];
   s_best[wv][lane] = best; s_bi[wv][lane] = bi;
   __syncthreads();
   if (wv != 0) return;
@@ -748,7 +773,7 @@ int acfm_bds_loss(const float* verts_xy, const float* bds, const uint8_t* vis, i
   if (!verts_xy || !bds || !vis || !loss || !argmin || N <= 0 || N > 65535 || V <= 0 || P <= 0 || ref_batch <= 0 ||
       N % ref_batch != 0)
     return ACFM_E_BADARG;
-  const size_t lds = sizeof(float) * 2 * (size_t)V;
+  const size_t lds = sizeof(float) * 3 * (size_t)V;   // (x, y) per vertex + the index a packed vertex came from
   if (lds > 150 * 1024) return ACFM_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(loss, sizeof(float) * (size_t)N, st) != ACFM_OK) return ACFM_E_LAUNCH;
