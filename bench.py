@@ -646,13 +646,16 @@ def run_config2_or_5(ctx):
         def render_only():
             mk, _ = renderer(rv, faces, rc)
             return torch.autograd.grad((mk * rw).sum(), [rv, rc])
+        rg, _ = (ctx.capture(render_only, "render_only") if use_graph else (None, None))
         dt_render = None
-        for _round in range(2):   # eager launches: one allocator hiccup would show
-            d_ = ctx.time_steps(render_only, half_w if _round == 0 else 0, a.steps)
+        for _round in range(2):   # (twice: one allocator hiccup of an eager run would show)
+            d_ = ctx.time_steps(rg.replay if rg is not None else render_only, half_w if _round == 0 else 0, a.steps)
             dt_render = d_ if dt_render is None else min(dt_render, d_)
+        ops.invalidate_setups()
         legs["render_only"] = ctx.leg(dt_render, N, a.steps,
                                       note="soft-silhouette render K=20 (pix_to_face [N,H,W,20] as the default lazy tensor) + backward to "
-                                           "vertices and cameras only; eager launches")
+                                           "vertices and cameras only",
+                                      launch="one hipGraph replay per step" if rg is not None else "eager")
 
     # ---- SURVEY section 8d's step, every row of it: the headline step + the per-optimiser-step factorisation
     # of the deformation system with learned handle weights (a8: cot Laplacian, fp64 Cholesky, lbs gradient)
