@@ -20,10 +20,22 @@ tools/pmc.sh $o/pmc5_f FETCH_SIZE -- $B5 > $o/${tag}_pmc_hbm_config5.txt 2>&1 ||
 tools/pmc.sh $o/pmc5_w WRITE_SIZE -- $B5 >> $o/${tag}_pmc_hbm_config5.txt 2>&1 || exit 1
 tools/pmc.sh $o/pmc5_sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -- $B5 > $o/${tag}_pmc_sq_config5.txt 2>&1 || exit 1
 python3 tools/pmc_traffic.py --frames 16 --img 512 --mesh horse_subdiv1 --storage f16 --command "$B5" $o/${tag}_pmc_hbm_config5.txt $o/${tag}_pmc_sq_config5.txt > $o/cfg5.json
-python3 - $o/${tag}_pmc_traffic.json $o/cfg5.json <<'PY'
+# ... and for configs 3 and 4 (their `roofline.traffic`): FETCH / WRITE + the VALU counters
+for c in 3 4; do
+  Bc="python3 bench.py --config $c --steps 10 --warmup 3 --headline-only --eager --no-cpu"
+  tools/pmc.sh $o/pmc${c}_f FETCH_SIZE -- $Bc > $o/${tag}_pmc_hbm_config$c.txt 2>&1 || exit 1
+  tools/pmc.sh $o/pmc${c}_w WRITE_SIZE -- $Bc >> $o/${tag}_pmc_hbm_config$c.txt 2>&1 || exit 1
+  tools/pmc.sh $o/pmc${c}_sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -- $Bc > $o/${tag}_pmc_sq_config$c.txt 2>&1 || exit 1
+done
+python3 tools/pmc_traffic.py --frames 32 --img 256 --mesh horse --storage f32 --command "python3 bench.py --config 3 ..." $o/${tag}_pmc_hbm_config3.txt $o/${tag}_pmc_sq_config3.txt > $o/cfg3.json
+python3 tools/pmc_traffic.py --frames 32 --img 256 --mesh mixed --storage f32 --command "python3 bench.py --config 4 ..." $o/${tag}_pmc_hbm_config4.txt $o/${tag}_pmc_sq_config4.txt > $o/cfg4.json
+python3 - $o/${tag}_pmc_traffic.json $o/cfg5.json $o/cfg3.json $o/cfg4.json <<'PY'
 import json, sys
-main, extra = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
-main["more"] = [{"workload": extra["workload"], "kernels": extra["kernels"], "source": extra["source"]}]
+main = json.load(open(sys.argv[1]))
+main["more"] = []
+for fn in sys.argv[2:]:
+    extra = json.load(open(fn))
+    main["more"].append({"workload": extra["workload"], "kernels": extra["kernels"], "source": extra["source"]})
 json.dump(main, open(sys.argv[1], "w"), indent=1)
 PY
 cp $o/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json   # the bench lines below cite this round's counters
