@@ -282,3 +282,47 @@ def test_sharded_multiframe_step_matches_the_full_batch(meshes, tmp_path):
     rows = batch["frames_idx"][0].cpu().numpy()
     np.testing.assert_allclose(got["cams"].numpy()[:, rows] / 2, cam_ref[:, rows], rtol=0, atol=2e-4 * np.abs(cam_ref).max())
     assert got["bytes"] == 8 * (642 * 6 + 3 * 642 + 1)
+
+
+def test_exchange_buffer_written_in_place_with_direct_terms(meshes):
+    """sharding.SharedShapeExchange on one process (world 1): the deformation apply's backward writes G = sum g delta^T and
+    sum g in double straight into the head of the exchange buffer; a DIRECT term on the mean shape (a prior on the
+    template), an extra shared parameter and two scalars ride in the same buffer.  finish() must give the gradients of
+    plain autograd through the solver (lbs within the conditioning of the solve's backward, the rest to float rounding)."""
+    from acfm_video_3d_reconstruction_amd.deform import DeformSolver
+    from acfm_video_3d_reconstruction_amd.sharding import SharedShapeExchange
+    from acfm_video_3d_reconstruction_amd.synthetic import fps_lbs_logits
+    d = _d()
+    rng = np.random.default_rng(21)
+    v, f = meshes["bird_v"], meshes["bird_f"]
+    N, Kh = 5, 8
+    delta = torch.tensor(rng.normal(0, 0.02, (N, Kh, 3)).astype(np.float32), device=d)
+    w = torch.tensor(rng.normal(0, 1, (N, v.shape[0], 3)).astype(np.float32), device=d)
+
+    def make():
+        lbs = torch.nn.Parameter(torch.tensor(fps_lbs_logits(v, Kh), device=d))
+        mean = torch.nn.Parameter(torch.tensor(v, device=d))
+        extra = torch.nn.Parameter(torch.tensor([0.3, -0.2], device=d))
+        return DeformSolver(mean, torch.tensor(f, device=d), lbs), extra
+
+    def loss_of(pred_v, solver, extra):
+        return (pred_v * w).sum() * (1.0 + extra[0]) + 0.5 * (solver.mean_v ** 2).sum() + extra[1] ** 2
+
+    ref_s, ref_e = make()
+    ref_s.refresh()
+    loss_of(ref_s(delta), ref_s, ref_e).backward()
+
+    s, e = make()
+    ex = SharedShapeExchange(s, extra_params=[e])
+    pred = ex.apply(delta)
+    loss = loss_of(pred, s, e)
+    loss.backward()                                    # (P, mean) leaves, the direct term on mean_v, the extra parameter
+    assert ex._filled and ex._store is not None        # the backward's kernel wrote the doubles in place
+    sc = ex.finish(extra_scalars=torch.stack([loss.detach(), loss.detach() * 2]))
+    assert ex.bytes == 8 * (v.shape[0] * Kh + 3 * v.shape[0] + 2 + 2)
+    np.testing.assert_allclose(sc.cpu().numpy(), [float(loss), 2 * float(loss)], rtol=1e-6)
+    np.testing.assert_allclose(e.grad.cpu().numpy(), ref_e.grad.cpu().numpy(), rtol=1e-6)
+    gm, rm = s.mean_v.grad.cpu().numpy(), ref_s.mean_v.grad.cpu().numpy()
+    np.testing.assert_allclose(gm, rm, rtol=0, atol=2e-6 * np.abs(rm).max())
+    gl, rl = s.lbs.grad.cpu().numpy(), ref_s.lbs.grad.cpu().numpy()
+    np.testing.assert_allclose(gl, rl, rtol=0, atol=2e-6 * np.abs(rl).max())
