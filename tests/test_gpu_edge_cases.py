@@ -279,3 +279,16 @@ def test_backward_groups_share_lopsided_blocks(meshes):
                 (mask * mask).sum().backward()
                 grads.append((tv.grad.clone(), tc.grad.clone()))
             assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("n", [64, 32, 5])
+def test_face_setup_slices_per_mesh(meshes, n):
+    """k_setup runs 4, 8 or 16 face slices (workgroups) per mesh depending on the batch (64+ / 32+ / fewer meshes:
+    RasterWs.slices), k_order adds that many count planes and, beyond four, joins the slices' mesh boxes: the three
+    layouts against the oracle (ids bit for bit, masks 1e-6, gradients 1e-4), small images."""
+    rng = np.random.default_rng(100 + n)
+    v, f = meshes["horse_v"], meshes["horse_f"]
+    verts = batch_verts(v, n, rng, 0.01)
+    cams = make_cams(n, rng, extent=float(np.abs(v).max()))
+    cams[::3, 1:3] += 0.4                       # some meshes partly outside
+    _check_sil(verts, f, cams, 40, seed=n)
